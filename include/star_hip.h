@@ -1,0 +1,187 @@
+/* star_hip.h -- C ABI of libstar_hip.so, the gfx950 (MI355X) kernels behind the STAR completion path.
+ *
+ * The reference (coperception/star) is pure Python/PyTorch and has no FFI; what each entry point
+ * REPLACES is therefore a PyTorch op sequence in the reference, cited per function as
+ * file:line under /root/reference.  A maintainer binds these with ctypes.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless its name starts with h_ ;
+ *   - the library never allocates or frees device memory and keeps no pointer after return:
+ *     inputs, outputs and workspaces are caller-allocated (PyTorch tensors in the host package);
+ *   - `stream` is a hipStream_t passed as void*; kernels are enqueued on it and nothing synchronises;
+ *   - return value: 0 = ok, negative = error; star_last_error() returns a thread-local message;
+ *   - no exception crosses the ABI; entry points are re-entrant (no global mutable state);
+ *   - `dt` selects the activation storage type: STAR_BF16 (bf16 storage, fp32 accumulation) or
+ *     STAR_F32 (fp32 storage and fp32 MFMA, the reference's numerics).
+ */
+#ifndef STAR_HIP_H
+#define STAR_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define STAR_BF16 0
+#define STAR_F32 1
+
+int star_version(void);
+const char* star_last_error(void);
+
+/* ---- K10: inter-agent pose warp + union fusion -------------------------------------------------
+ * Replaces late_fusion / ego_late_fusion (star/models/multiagent_mae.py:870-944), which loops in
+ * Python over scenes/agents calling feature_transformation (star/models/mae_base.py:589-614: two
+ * affine_grid + two grid_sample(mode='nearest')) and fusion('union') (mae_base.py:624-633).
+ *   pred      uint8 [A*B, C, H, W] agent-major (row a*B+b), the per-agent 0/1 occupancy decisions
+ *   ego       optional float32 maps used for the ego slot instead of pred (inference: the agent's own
+ *             input); element strides (in floats) ego_sn, ego_sc, ego_sh, ego_sw; NULL in training
+ *   theta     float32 [B, A, A, 8]: for (b, ego i, neighbour j) the six rotation-theta entries that
+ *             matter (r00 r01 r10 r11) followed by (x_trans, y_trans) and two pads, formed on the host
+ *             in the source dtype of trans_matrices and then cast (mae_base.py:595-606)
+ *   num_agent int32/int64 [B, A] on the device (only [b,0] is read, as multiagent_mae.py:887)
+ *   out       float32 [A*B, C, H, W]
+ * Bit-exact with the reference CPU path (half-to-even rounding, zero padding, k-ordered fma chain). */
+int star_warp_fuse(const uint8_t* pred, const float* ego, int64_t ego_sn, int64_t ego_sc, int64_t ego_sh,
+                   int64_t ego_sw, const float* theta, const void* num_agent, int num_agent_is64,
+                   float* out, int B, int A, int C, int H, int W, void* stream);
+
+/* ---- K5: mask index build ------------------------------------------------------------------------
+ * Replaces ids_shuffle = argsort(noise); ids_restore = argsort(ids_shuffle)
+ * (multiagent_mae.py:811-814, mae_base.py:417-421).  noise float32 [R, L] (L <= 4096); stable.
+ * Outputs int64 [R, L] each (either may be NULL). */
+int star_mask_sort(const float* noise, int64_t* ids_shuffle, int64_t* ids_restore, int R, int L, void* stream);
+
+/* Row maps for the sub-sampling gather / temporal un-mixing, built on the device from the ids.
+ * Replaces the gather/cat/slice index arithmetic of amortized_complement_masking/_unmasking
+ * (multiagent_mae.py:816-867) and random_masking / amortized_random_unmasking
+ * (mae_base.py:423-431, multiagent_mae.py:761-796).
+ *  complement: keep = ceil(L/T).
+ *    src_row [BA*T*keep] : row of the [BA*T*L] token matrix that feeds compressed row r, or -1 (pad)
+ *    dst_row [BA*T*keep] : row of the [BA*L] decoder input that compressed row r lands on, or -1
+ *                          (pad; with `single`, rows of timestamps > 0 are dropped too)
+ *    mask    float32 [BA, T, L] (0 = kept) or NULL
+ *    fill    int32 [BA*L] : 1 where the decoder input row is NOT covered (gets mask_token), else 0
+ *  random: keep = int(L*(1-ratio)); ids_* are [BA*T, L].
+ *    dst_row picks, for every token, the first timestamp that kept it (multiagent_mae.py:791-796). */
+int star_build_rowmaps(const int64_t* ids_shuffle, const int64_t* ids_restore, int32_t* src_row,
+                       int32_t* dst_row, float* mask, int32_t* fill, int BA, int T, int L, int keep,
+                       int random_mode, int single, void* stream);
+
+/* ---- K2: LayerNorm ---------------------------------------------------------------------------------
+ * Replaces nn.LayerNorm(eps=1e-6) inside timm Block and self.norm / self.decoder_norm
+ * (mae_base.py:279-282,308-312; multiagent_mae.py:976-978,1044-1046).
+ * x float32 [M, D] (the residual stream), y [M, D] in `dt`, mean/rstd float32 [M]. */
+int star_layernorm_fwd(const float* x, const float* gamma, const float* beta, void* y, float* mean,
+                       float* rstd, int M, int D, float eps, int dt, void* stream);
+/* dx = LN'(dy); g_out = (g_in ? g_in : 0) + dx in float32, plus an optional copy g_out_lp in `dt`.
+ * dgamma/dbeta are written (not accumulated); ws float32 [star_layernorm_bwd_ws(D)]. */
+int64_t star_layernorm_bwd_ws(int D);
+int star_layernorm_bwd(const void* dy, const float* x, const float* gamma, const float* mean,
+                       const float* rstd, const float* g_in, float* g_out, void* g_out_lp, float* dgamma,
+                       float* dbeta, float* ws, int M, int D, int dt, void* stream);
+
+/* ---- K3: Linear layers -------------------------------------------------------------------------------
+ * Replaces every nn.Linear on the path (timm Attention.qkv/proj, Mlp.fc1/fc2, compressor,
+ * decompressor, decoder_embed, decoder_pred_occ/free; mae_base.py:279-317) and, with the patch
+ * gather of star_patchify, the Conv2d patch embedding (mae_base.py:269).
+ * C[m, n] = epilogue( sum_k A[arow(m), k] * W[n, k] ), A [*, K] and W [N, K] in `dt`, K % 8 == 0. */
+typedef struct StarGemm {
+    const void* A;          /* [rows, K] dt */
+    const void* W;          /* [N, K] dt */
+    const int32_t* a_rows;  /* optional [M]: A row per output row, -1 = zero row */
+    const int32_t* c_rows;  /* optional [M]: destination row per output row, -1 = drop */
+    const float* bias;      /* optional [N] */
+    const float* res;       /* optional float32 [res_mod or M, N]: added after the activation */
+    int32_t res_mod;        /* >0: residual row = destination row % res_mod */
+    const float* res2;      /* optional float32 [res2_div-indexed rows, N]: row = (m / res2_div) % res2_mod */
+    int32_t res2_div, res2_mod;
+    const void* aux;        /* optional dt [M, N] used by ACT_DGELU / ACT_DRELU (pre-activation / output) */
+    int32_t act;            /* STAR_ACT_* */
+    void* pre;              /* optional dt [M, N]: value before the activation */
+    void* out_lp;           /* optional dt [M(dest), N] */
+    float* out_f32;         /* optional float32 [M(dest), N] */
+    int32_t M, N, K;
+    int32_t dt;
+} StarGemm;
+#define STAR_ACT_NONE 0
+#define STAR_ACT_GELU 1   /* exact erf GELU (timm Mlp act_layer=nn.GELU) */
+#define STAR_ACT_RELU 2   /* compressor ReLU (mae_base.py:284-287) */
+#define STAR_ACT_DGELU 3  /* backward: multiply by gelu'(aux) */
+#define STAR_ACT_DRELU 4  /* backward: multiply by (aux > 0) */
+int star_gemm(const StarGemm* g, void* stream);
+
+/* Weight gradient: dW[n, k] = sum_m dY[m, n] * X[xrow(m), k]  (float32, written), optional
+ * db[n] = sum_m dY[m, n].  dY [M, N], X [*, K] in `dt`.  ws float32 [star_gemm_wgrad_ws(M,N,K)]. */
+int64_t star_gemm_wgrad_ws(int M, int N, int K);
+int star_gemm_wgrad(const void* dY, const void* X, const int32_t* x_rows, float* dW, float* db, float* ws,
+                    int M, int N, int K, int dt, void* stream);
+
+/* ---- K4: attention -----------------------------------------------------------------------------------
+ * Replaces timm Attention.forward between qkv and proj: softmax(q k^T hd^-0.5) v, no mask, no
+ * dropout.  qkv [NB, L, 3, H, hd] in `dt` (the qkv Linear output as it lies in memory), out
+ * [NB, L, H*hd] in `dt`, lse float32 [NB, H, L] (log2-domain row log-sum-exp, kept for backward).
+ * hd in {16, 32, 64}; any L >= 1. */
+int star_attn_fwd(const void* qkv, void* out, float* lse, int NB, int L, int H, int hd, int dt, void* stream);
+/* dqkv [NB, L, 3, H, hd] from dout [NB, L, H*hd]; delta float32 [NB, H, L] is workspace. */
+int star_attn_bwd(const void* qkv, const void* out, const void* dout, const float* lse, float* delta,
+                  void* dqkv, int NB, int L, int H, int hd, int dt, void* stream);
+
+/* ---- K1: voxel -> patch gather ------------------------------------------------------------------------
+ * Replaces the im2col half of Conv2d(13, D, k=p, s=p) + flatten(2).transpose(1,2) (timm PatchEmbed;
+ * mae_base.py:269, multiagent_mae.py:960-962).  Frame f = ba*T + t is imgs1[ba] for t = 0 and
+ * imgs_next[ba, t-1] otherwise; both are float32 with element strides (the reference hands over
+ * NHWC memory viewed as NCHW, CoModule.py:93-96).  out [BA*T*(H/p)*(W/p), C*p*p] in `dt`, patch vector
+ * order (c, py, px) = the Conv2d weight's own flattening. */
+int star_patchify(const float* img1, const int64_t* s1 /*[4] n,c,h,w*/, const float* imgn,
+                  const int64_t* sn /*[5] n,t,c,h,w*/, void* out, int BA, int T, int C, int H, int W, int p,
+                  int dt, void* stream);
+
+/* ---- K9: occupancy loss + decision ----------------------------------------------------------------------
+ * Replaces CrossEntropyLoss over the class dim + argmax(softmax) (multiagent_mae.py:1076-1079,1099)
+ * and the unpatchify/stack in front of them (mae_base.py:392-406, multiagent_mae.py:1051-1057).
+ * logits float32 [BA*L, 2*V] in patch layout, V = C*p*p, column = cls*V + (c*p + py)*p + px
+ * (cls 0 = free, 1 = occupied; the host permutes the head weights' rows into this order).
+ * target float32 image with element strides.  Outputs (each optional):
+ *   ind64 int64 [BA,C,H,W], ind8 uint8 [BA,C,H,W], pred float32 [BA,2,C,H,W] (the reference's layout),
+ *   dlogits dt [BA*L, 2*V] = (softmax - onehot) / (BA*C*H*W),
+ *   loss_partial float32 [star_ce_nblocks(...)] per-block sums; star_ce_finish folds them into
+ *   loss[0] = mean CE in fixed order. */
+int star_ce_nblocks(int BA, int C, int H, int W);
+int star_ce_argmax(const float* logits, const float* target, const int64_t* st /*[4]*/, int64_t* ind64,
+                   uint8_t* ind8, float* pred, void* dlogits, float* loss_partial, int BA, int C, int H,
+                   int W, int p, int dt, void* stream);
+int star_ce_finish(const float* loss_partial, int nblocks, int64_t count, float* loss, void* stream);
+
+/* ---- K7 helper: rows the temporal un-mixing does not cover get mask_token (+temp embed of t=0) + pos.
+ * x float32 [BA*L, D]; fill int32 [BA*L] from star_build_rowmaps. */
+int star_fill_rows(float* x, const int32_t* fill, const float* mask_token, const float* temp0,
+                   const float* pos, int BA, int L, int D, void* stream);
+/* Q2 (multiagent_mae.py:797 -> :1037): the random-mode decoder input is the [BA, L, D] token matrix
+ * transposed to [BA, D, L] and re-read as [BA, L, D]; then + pos.  src/dst float32. */
+int star_transpose_rows(const float* src, float* dst, const float* pos, int BA, int L, int D, void* stream);
+int star_transpose_rows_bwd(const float* gdst, float* gsrc, int BA, int L, int D, void* stream);
+
+/* ---- parameter plumbing -----------------------------------------------------------------------------------
+ * cast float32 -> dt for many tensors in one launch is done by star_cast; star_colsum gives bias grads. */
+int star_cast(const float* src, void* dst, int64_t n, int dt, void* stream);
+int star_cast_back(const void* src, float* dst, int64_t n, int dt, void* stream);
+/* AdamW (decoupled weight decay) over one flat float32 buffer, torch.optim.AdamW semantics
+ * (train_completion.py:125): p -= lr*wd*p; m,v updates; p -= lr/bc1 * m / (sqrt(v)/sqrt(bc2) + eps).
+ * wd_mask uint8 per element (1 = decay) or NULL; gscale optional device scalar multiplied into g. */
+int star_adamw(float* p, const float* g, float* m, float* v, const uint8_t* wd_mask, const float* gscale,
+               int64_t n, float lr, float beta1, float beta2, float eps, float wd, int step, void* stream);
+/* sum of squares of a flat float32 buffer -> out[0] (deterministic two-stage); ws float32 [1024]. */
+int star_sumsq(const float* x, int64_t n, float* ws, float* out, void* stream);
+
+/* ---- K11: occupancy IoU confusion counts ----------------------------------------------------------------
+ * Replaces Metrics.add_batch (star/utils/metrics.py:146-190): threshold >= 0.5, MaxPool3d((2,2,2),
+ * stride 2, padding (1,0,0)) twice, 2x2 confusion per scale.  pred/target float32 [N, Z, H, W]
+ * contiguous; conf int64 [3, 2, 2] (rows = prediction) is ADDED to (zero it first). */
+int star_iou_confusion(const float* pred, const float* target, unsigned long long* conf, int N, int Z, int H,
+                       int W, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

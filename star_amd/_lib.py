@@ -1,0 +1,105 @@
+"""ctypes binding of libstar_hip.so (declared in include/star_hip.h).
+
+The product path has no CPU fallback: if the shared library is missing or a call fails, an exception is
+raised.  Tensors are passed as raw device pointers plus sizes; kernels are enqueued on torch's current
+HIP stream.
+"""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libstar_hip.so")
+
+BF16, F32 = 0, 1
+ACT_NONE, ACT_GELU, ACT_RELU, ACT_DGELU, ACT_DRELU = 0, 1, 2, 3, 4
+
+_lib = None
+
+
+class StarGemm(C.Structure):
+    _fields_ = [
+        ("A", C.c_void_p), ("W", C.c_void_p), ("a_rows", C.c_void_p), ("c_rows", C.c_void_p),
+        ("bias", C.c_void_p), ("res", C.c_void_p), ("res_mod", C.c_int32),
+        ("res2", C.c_void_p), ("res2_div", C.c_int32), ("res2_mod", C.c_int32),
+        ("aux", C.c_void_p), ("act", C.c_int32), ("pre", C.c_void_p), ("out_lp", C.c_void_p),
+        ("out_f32", C.c_void_p), ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32), ("dt", C.c_int32),
+    ]
+
+
+_P, _I, _L, _F = C.c_void_p, C.c_int, C.c_int64, C.c_float
+_SIGS = {
+    "star_version": (C.c_int, []),
+    "star_last_error": (C.c_char_p, []),
+    "star_warp_fuse": (C.c_int, [_P, _P, _L, _L, _L, _L, _P, _P, _I, _P, _I, _I, _I, _I, _I, _P]),
+    "star_mask_sort": (C.c_int, [_P, _P, _P, _I, _I, _P]),
+    "star_build_rowmaps": (C.c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "star_layernorm_fwd": (C.c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _F, _I, _P]),
+    "star_layernorm_bwd_ws": (C.c_int64, [_I]),
+    "star_layernorm_bwd": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
+    "star_gemm": (C.c_int, [C.POINTER(StarGemm), _P]),
+    "star_gemm_wgrad_ws": (C.c_int64, [_I, _I, _I]),
+    "star_gemm_wgrad": (C.c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "star_attn_fwd": (C.c_int, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "star_attn_bwd": (C.c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "star_patchify": (C.c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "star_ce_nblocks": (C.c_int, [_I, _I, _I, _I]),
+    "star_ce_argmax": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "star_ce_finish": (C.c_int, [_P, _I, _L, _P, _P]),
+    "star_fill_rows": (C.c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _P]),
+    "star_transpose_rows": (C.c_int, [_P, _P, _P, _I, _I, _I, _P]),
+    "star_transpose_rows_bwd": (C.c_int, [_P, _P, _I, _I, _I, _P]),
+    "star_cast": (C.c_int, [_P, _P, _L, _I, _P]),
+    "star_cast_back": (C.c_int, [_P, _P, _L, _I, _P]),
+    "star_adamw": (C.c_int, [_P, _P, _P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _I, _P]),
+    "star_sumsq": (C.c_int, [_P, _L, _P, _P, _P]),
+    "star_iou_confusion": (C.c_int, [_P, _P, _P, _I, _I, _I, _I, _P]),
+}
+EXPORTS = tuple(_SIGS)
+
+
+def lib():
+    """Load libstar_hip.so once.  Raises if it has not been built (python __graft_entry__.py build)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError("star_amd: %s is missing -- build it with `make -C star_amd/csrc` "
+                               "(there is no CPU fallback for the HIP path)" % LIB_PATH)
+        handle = C.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(handle, name)
+            fn.restype, fn.argtypes = res, args
+        _lib = handle
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        raise RuntimeError("libstar_hip: " + lib().star_last_error().decode())
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def p(t):
+    """Device pointer of a tensor (None -> NULL)."""
+    return None if t is None else t.data_ptr()
+
+
+def strides(t):
+    """int64 ctypes array of element strides."""
+    return (C.c_int64 * t.dim())(*t.stride())
+
+
+def dt_of(t):
+    if t.dtype == torch.bfloat16:
+        return BF16
+    if t.dtype == torch.float32:
+        return F32
+    raise TypeError("activation dtype must be bfloat16 or float32, got %s" % t.dtype)
+
+
+def torch_dtype(dt):
+    return torch.bfloat16 if dt == BF16 else torch.float32

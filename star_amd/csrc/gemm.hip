@@ -1,0 +1,536 @@
+// K3: every Linear layer of the path as one MFMA GEMM family for gfx950.
+//
+//   star_gemm        C[m,n] = epilogue( sum_k A[arow(m),k] * W[n,k] )      ("NT": both K-contiguous)
+//   star_gemm_wgrad  dW[n,k] = sum_m dY[m,n] * X[xrow(m),k]                ("TN": reduction over rows)
+//
+// Reference ops replaced: nn.Linear in timm Attention/Mlp and the compressor / decompressor /
+// decoder_embed / prediction heads (star/models/mae_base.py:279-317), and their autograd backward.
+//
+// Design (bf16 storage, fp32 accumulate):
+//   * 256 threads = 4 waves (2x2); v_mfma_f32_16x16x32_bf16; the WEIGHT tile is the MFMA A operand
+//     and the activation tile the B operand, so each lane ends up with 4 consecutive output columns
+//     of one row: the epilogue (bias, GELU/ReLU, residuals, row scatter) works on 16-byte vectors.
+//   * BK = 64; operand tiles go global -> registers -> LDS (double-buffered LDS, one barrier per
+//     k-step, next tile's global loads in flight during the MFMAs).
+//   * LDS rows are 128 B; 16-byte chunk c of row r is stored at chunk c ^ ((r>>1)&7): conflict-free
+//     for both the ds_write_b128 fill and the ds_read_b128 fragment reads (guide section 2 banking).
+//   * The TN kernel stages [m][n] / [m][k] tiles as they lie in memory and reads fragments with
+//     ds_read_b64_tr_b16 (hardware transpose), slots XOR-swizzled by (row&3)|((row>>3&1)<<2).
+//   * block id -> tile with an XCD-aware bijective remap: the n-tiles of one m-tile run on one XCD
+//     and share its L2 copy of the activation tile.
+//   * Split-M in the TN kernel writes fp32 slabs reduced in a fixed order (deterministic gradients).
+// The fp32 path (STAR_F32) uses v_mfma_f32_16x16x4_f32 on the same skeleton with BK = 32.
+#include "common.h"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(8))) short short8_t;
+typedef __attribute__((ext_vector_type(4))) short short4_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+
+#define GT 256  // threads
+
+__device__ __forceinline__ int xcd_remap(int bid, int nblk) {
+    // blocks b, b+8, ... share an XCD; give each XCD a contiguous chunk of tile ids (bijective)
+    const int q = nblk >> 3, r = nblk & 7, x = bid & 7, i = bid >> 3;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
+}
+
+__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float dgelu_f(float x) {
+    return 0.5f * (1.0f + erff(x * 0.70710678118654752f)) + x * 0.3989422804014327f * expf(-0.5f * x * x);
+}
+
+// ------------------------------------------------------------------------------------------------------
+// element traits: how many elements a 16-byte chunk holds and how a k-step is fed to the matrix core
+template <typename T> struct GemmT;
+template <> struct GemmT<bf16_t> {
+    static constexpr int EPC = 8;    // elements per 16-byte chunk
+    static constexpr int BK = 64;    // k-tile
+};
+template <> struct GemmT<float> {
+    static constexpr int EPC = 4;
+    static constexpr int BK = 32;
+};
+
+// LDS tile: rows of 128 B = 8 chunks of 16 B, chunk swizzled by ((row>>1)&7)
+__device__ __forceinline__ int lds_off(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
+
+template <typename T, int TM, int TN>
+__global__ __launch_bounds__(GT) void gemm_nt_kernel(const StarGemm g) {
+    constexpr int BM = 32 * TM, BN = 32 * TN;
+    constexpr int EPC = GemmT<T>::EPC, BK = GemmT<T>::BK;
+    constexpr int A_IT = BM * 8 / GT, W_IT = (BN * 8 + GT - 1) / GT;  // 16-byte chunks per thread per tile
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int STAGE = (BM + BN) * 128;  // bytes per pipeline stage: A tile then W tile
+
+    const int M = g.M, N = g.N, K = g.K;
+    const int tiles_n = (N + BN - 1) / BN, tiles_m = (M + BM - 1) / BM;
+    const int tile = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+    const int m_blk = (tile / tiles_n) * BM, n_blk = (tile % tiles_n) * BN;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave & 1, wn = wave >> 1;
+    const int lr = lane & 15, lg = lane >> 4;
+
+    const T* A = (const T*)g.A;
+    const T* W = (const T*)g.W;
+
+    // global -> register staging: thread owns chunk (tid & 7) of rows (tid >> 3) + 32*i
+    const int ld_chunk = tid & 7, ld_row = tid >> 3;
+    const T* a_ptr[A_IT];
+    const T* w_ptr[W_IT];
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i) {
+        const int m = m_blk + ld_row + 32 * i;
+        long long src = -1;
+        if (m < M) src = g.a_rows ? (long long)g.a_rows[m] : (long long)m;
+        a_ptr[i] = src >= 0 ? A + (size_t)src * K + ld_chunk * EPC : nullptr;
+    }
+#pragma unroll
+    for (int i = 0; i < W_IT; ++i) {
+        const int n = n_blk + ld_row + 32 * i;
+        w_ptr[i] = (n < N && ld_row + 32 * i < BN) ? W + (size_t)n * K + ld_chunk * EPC : nullptr;
+    }
+    uint4 ra[A_IT], rw[W_IT];
+    auto load_tile = [&](int k0) {
+        const bool kin = k0 + ld_chunk * EPC < K;
+#pragma unroll
+        for (int i = 0; i < A_IT; ++i)
+            ra[i] = (a_ptr[i] && kin) ? *reinterpret_cast<const uint4*>(a_ptr[i] + k0) : make_uint4(0, 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < W_IT; ++i)
+            rw[i] = (w_ptr[i] && kin) ? *reinterpret_cast<const uint4*>(w_ptr[i] + k0) : make_uint4(0, 0, 0, 0);
+    };
+    auto store_tile = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < A_IT; ++i) *reinterpret_cast<uint4*>(smem + buf * STAGE + lds_off(ld_row + 32 * i, ld_chunk)) = ra[i];
+#pragma unroll
+        for (int i = 0; i < W_IT; ++i)
+            if (ld_row + 32 * i < BN) *reinterpret_cast<uint4*>(smem + buf * STAGE + BM * 128 + lds_off(ld_row + 32 * i, ld_chunk)) = rw[i];
+    };
+
+    f32x4_t acc[TN][TM];
+#pragma unroll
+    for (int a = 0; a < TN; ++a)
+#pragma unroll
+        for (int b = 0; b < TM; ++b) acc[a][b] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+    const int nk = (K + BK - 1) / BK;
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) load_tile((kt + 1) * BK);
+        const unsigned char* pa = smem + buf * STAGE;
+        const unsigned char* pw = pa + BM * 128;
+        if constexpr (sizeof(T) == 2) {
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {  // two 32-deep MFMA steps per 64-deep tile
+                short8_t fw[TN], fx[TM];
+#pragma unroll
+                for (int a = 0; a < TN; ++a)
+                    fw[a] = *reinterpret_cast<const short8_t*>(pw + lds_off(wn * TN * 16 + a * 16 + lr, ks * 4 + lg));
+#pragma unroll
+                for (int b = 0; b < TM; ++b)
+                    fx[b] = *reinterpret_cast<const short8_t*>(pa + lds_off(wm * TM * 16 + b * 16 + lr, ks * 4 + lg));
+#pragma unroll
+                for (int a = 0; a < TN; ++a)
+#pragma unroll
+                    for (int b = 0; b < TM; ++b)
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, fw[a]),
+                                                                            __builtin_bit_cast(bf16x8_t, fx[b]), acc[a][b], 0, 0, 0);
+            }
+        } else {
+            // fp32: v_mfma_f32_16x16x4_f32 takes one value per lane (k = lane>>4).  A 16-byte chunk
+            // holds 4 consecutive k; lane group lg reads chunk (2*ks*... ) so that the four MFMAs of a
+            // chunk-quad use k = 4*lg + j on both operands (any consistent k permutation is valid).
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {  // 2 x 16 k per 32-deep tile
+                f32x4_t fw[TN], fx[TM];
+#pragma unroll
+                for (int a = 0; a < TN; ++a)
+                    fw[a] = *reinterpret_cast<const f32x4_t*>(pw + lds_off(wn * TN * 16 + a * 16 + lr, ks * 4 + lg));
+#pragma unroll
+                for (int b = 0; b < TM; ++b)
+                    fx[b] = *reinterpret_cast<const f32x4_t*>(pa + lds_off(wm * TM * 16 + b * 16 + lr, ks * 4 + lg));
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int a = 0; a < TN; ++a)
+#pragma unroll
+                        for (int b = 0; b < TM; ++b)
+                            acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(fw[a][j], fx[b][j], acc[a][b], 0, 0, 0);
+            }
+        }
+        if (kt + 1 < nk) store_tile(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: lane holds C[m][n0..n0+3], m = .. + lr, n0 = .. + lg*4
+    T* out_lp = (T*)g.out_lp;
+    T* pre = (T*)g.pre;
+    const T* aux = (const T*)g.aux;
+#pragma unroll
+    for (int b = 0; b < TM; ++b) {
+        const int m = m_blk + wm * TM * 16 + b * 16 + lr;
+        if (m >= M) continue;
+        const long long d = g.c_rows ? (long long)g.c_rows[m] : (long long)m;
+        if (d < 0) continue;
+#pragma unroll
+        for (int a = 0; a < TN; ++a) {
+            const int n0 = n_blk + wn * TN * 16 + a * 16 + lg * 4;
+            if (n0 >= N) continue;
+            float v[4] = {acc[a][b][0], acc[a][b][1], acc[a][b][2], acc[a][b][3]};
+            if (g.bias) {
+                float t[4];
+                ld4(g.bias + n0, t);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] += t[e];
+            }
+            if (pre) st4(pre + (size_t)d * N + n0, v);
+            if (g.act == STAR_ACT_GELU) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = gelu_f(v[e]);
+            } else if (g.act == STAR_ACT_RELU) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+            } else if (g.act == STAR_ACT_DGELU) {
+                float t[4];
+                ld4(aux + (size_t)m * N + n0, t);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] *= dgelu_f(t[e]);
+            } else if (g.act == STAR_ACT_DRELU) {
+                float t[4];
+                ld4(aux + (size_t)m * N + n0, t);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = t[e] > 0.f ? v[e] : 0.f;
+            }
+            if (g.res) {
+                const long long rr = g.res_mod > 0 ? d % g.res_mod : d;
+                float t[4];
+                ld4(g.res + (size_t)rr * N + n0, t);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] += t[e];
+            }
+            if (g.res2) {
+                const int rr = (m / g.res2_div) % g.res2_mod;
+                float t[4];
+                ld4(g.res2 + (size_t)rr * N + n0, t);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] += t[e];
+            }
+            if (out_lp) st4(out_lp + (size_t)d * N + n0, v);
+            if (g.out_f32) st4(g.out_f32 + (size_t)d * N + n0, v);
+        }
+    }
+}
+
+template <typename T, int TM, int TN>
+static int launch_nt(const StarGemm* g, hipStream_t s) {
+    constexpr int BM = 32 * TM, BN = 32 * TN;
+    const int tiles = cdiv(g->M, BM) * cdiv(g->N, BN);
+    const size_t lds = (size_t)2 * (BM + BN) * 128;
+    hipLaunchKernelGGL((gemm_nt_kernel<T, TM, TN>), dim3(tiles), dim3(GT), lds, s, *g);
+    return 0;
+}
+
+extern "C" int star_gemm(const StarGemm* g, void* stream) {
+    STAR_CHECK(g && g->A && g->W, "star_gemm: null operand");
+    STAR_CHECK(g->M >= 0 && g->N > 0 && g->K > 0, "star_gemm: bad shape M=%d N=%d K=%d", g->M, g->N, g->K);
+    STAR_CHECK(g->dt == STAR_BF16 || g->dt == STAR_F32, "star_gemm: unknown dtype %d", g->dt);
+    const int epc = g->dt == STAR_BF16 ? 8 : 4;
+    STAR_CHECK(g->K % epc == 0, "star_gemm: K=%d must be a multiple of %d", g->K, epc);
+    STAR_CHECK(g->N % 4 == 0, "star_gemm: N=%d must be a multiple of 4", g->N);
+    STAR_CHECK(g->out_lp || g->out_f32 || g->pre, "star_gemm: no output");
+    STAR_CHECK(!(g->act == STAR_ACT_DGELU || g->act == STAR_ACT_DRELU) || g->aux, "star_gemm: activation gradient needs aux");
+    STAR_CHECK(!g->res2 || (g->res2_div > 0 && g->res2_mod > 0), "star_gemm: res2 needs div/mod");
+    if (g->M == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    const bool narrow = g->N <= 32;
+    if (g->dt == STAR_BF16) {
+        if (narrow) launch_nt<bf16_t, 4, 1>(g, s); else launch_nt<bf16_t, 4, 4>(g, s);
+    } else {
+        if (narrow) launch_nt<float, 4, 1>(g, s); else launch_nt<float, 4, 4>(g, s);
+    }
+    STAR_LAUNCH_CHECK("star_gemm");
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// TN: dW[n, k] = sum_m dY[m, n] * X[xrow(m), k].  Output tile 128(k) x 128(n); the MFMA A operand is
+// X^T (rows = k), the B operand dY (cols = n): each lane ends with 4 consecutive k of one n.
+// LDS tiles are [64 rows of m][128 columns] bf16 (256-B rows), 32-byte slots XOR-swizzled.
+#define WG_BKM 64
+#define WG_TILE 128
+
+__device__ __forceinline__ int tn_swz(int row) { return (row & 3) | (((row >> 3) & 1) << 2); }
+__device__ __forceinline__ int tn_off(int row, int slot) { return row * 256 + ((slot ^ tn_swz(row)) << 5); }
+
+__device__ __forceinline__ short4_t ds_read_tr16(const unsigned char* p) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4_t*)(p));
+}
+
+__global__ __launch_bounds__(GT) void gemm_tn_bf16_kernel(const bf16_t* __restrict__ dY, const bf16_t* __restrict__ X,
+                                                          const int32_t* __restrict__ x_rows, float* __restrict__ out,
+                                                          int M, int N, int K, int m_per_split) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int TILE_BYTES = WG_BKM * 256;
+
+    const int tiles_n = (N + WG_TILE - 1) / WG_TILE;
+    const int n_blk = (blockIdx.x % tiles_n) * WG_TILE, k_blk = (blockIdx.x / tiles_n) * WG_TILE;
+    const int split = blockIdx.y;
+    const int m_begin = split * m_per_split;
+    const int m_end = min(M, m_begin + m_per_split);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wk = wave & 1, wn = wave >> 1;  // wave tile: 64 k x 64 n
+
+    // staging: 64 rows x 16 chunks (16 B) per operand tile = 1024 chunks, 4 per thread
+    const int ld_chunk = tid & 15, ld_row = tid >> 4;  // rows ld_row + 16*i
+    uint4 ry[4], rx[4];
+    const bool yin = n_blk + ld_chunk * 8 < N, xin = k_blk + ld_chunk * 8 < K;
+    auto load_tile = [&](int m0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int m = m0 + ld_row + 16 * i;
+            ry[i] = make_uint4(0, 0, 0, 0);
+            rx[i] = make_uint4(0, 0, 0, 0);
+            if (m < m_end) {
+                if (yin) ry[i] = *reinterpret_cast<const uint4*>(dY + (size_t)m * N + n_blk + ld_chunk * 8);
+                if (xin) {
+                    const long long xr = x_rows ? (long long)x_rows[m] : (long long)m;
+                    if (xr >= 0) rx[i] = *reinterpret_cast<const uint4*>(X + (size_t)xr * K + k_blk + ld_chunk * 8);
+                }
+            }
+        }
+    };
+    auto store_tile = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = ld_row + 16 * i;
+            const int off = tn_off(row, ld_chunk >> 1) + ((ld_chunk & 1) << 4);
+            *reinterpret_cast<uint4*>(smem + buf * 2 * TILE_BYTES + off) = ry[i];
+            *reinterpret_cast<uint4*>(smem + buf * 2 * TILE_BYTES + TILE_BYTES + off) = rx[i];
+        }
+    };
+
+    f32x4_t acc[4][4];  // [k tile][n tile]
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+    // transposed-read addressing: 16-lane group lg covers m rows 8*lg..8*lg+7 of a 32-row step;
+    // lane 4q+p of the group supplies row q, columns 4p..4p+3 of a 16-column slot.
+    const int lg = lane >> 4, lq = (lane & 15) >> 2, lp = lane & 3;
+
+    const int nsteps = (m_end - m_begin + WG_BKM - 1) / WG_BKM;
+    if (nsteps > 0) {
+        load_tile(m_begin);
+        store_tile(0);
+    }
+    __syncthreads();
+    for (int st = 0; st < nsteps; ++st) {
+        const int buf = st & 1;
+        if (st + 1 < nsteps) load_tile(m_begin + (st + 1) * WG_BKM);
+        const unsigned char* pY = smem + buf * 2 * TILE_BYTES;
+        const unsigned char* pX = pY + TILE_BYTES;
+#pragma unroll
+        for (int ms = 0; ms < 2; ++ms) {  // two 32-row MFMA steps per 64-row tile
+            short8_t fx[4], fy[4];
+            const int r0 = ms * 32 + lg * 8 + lq;
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                const int slot = wk * 4 + a;
+                const short4_t lo = ds_read_tr16(pX + tn_off(r0, slot) + lp * 8);
+                const short4_t hi = ds_read_tr16(pX + tn_off(r0 + 4, slot) + lp * 8);
+                fx[a] = (short8_t){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            }
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const int slot = wn * 4 + b;
+                const short4_t lo = ds_read_tr16(pY + tn_off(r0, slot) + lp * 8);
+                const short4_t hi = ds_read_tr16(pY + tn_off(r0 + 4, slot) + lp * 8);
+                fy[b] = (short8_t){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            }
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, fx[a]),
+                                                                        __builtin_bit_cast(bf16x8_t, fy[b]), acc[a][b], 0, 0, 0);
+        }
+        if (st + 1 < nsteps) store_tile(buf ^ 1);
+        __syncthreads();
+    }
+    // D[i = k][j = n]: lane holds n = .. + (lane & 15), k = .. + (lane >> 4) * 4 + e
+    float* o = out + (size_t)split * N * K;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        const int n = n_blk + wn * 64 + b * 16 + (lane & 15);
+        if (n >= N) continue;
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            const int k0 = k_blk + wk * 64 + a * 16 + lg * 4;
+            if (k0 >= K) continue;
+            *reinterpret_cast<float4*>(o + (size_t)n * K + k0) = make_float4(acc[a][b][0], acc[a][b][1], acc[a][b][2], acc[a][b][3]);
+        }
+    }
+}
+
+// fp32 TN path: simple LDS-tiled kernel on v_mfma_f32_16x16x4_f32; one value per lane per operand.
+// Tile 64(k) x 64(n), 4 waves each 32x32, reduction step 16 rows.
+__global__ __launch_bounds__(GT) void gemm_tn_f32_kernel(const float* __restrict__ dY, const float* __restrict__ X,
+                                                         const int32_t* __restrict__ x_rows, float* __restrict__ out,
+                                                         int M, int N, int K, int m_per_split) {
+    __shared__ float sY[16][64 + 4], sX[16][64 + 4];
+    const int tiles_n = (N + 63) / 64;
+    const int n_blk = (blockIdx.x % tiles_n) * 64, k_blk = (blockIdx.x / tiles_n) * 64;
+    const int split = blockIdx.y;
+    const int m_begin = split * m_per_split, m_end = min(M, m_begin + m_per_split);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wk = wave & 1, wn = wave >> 1;
+    const int ld_row = tid >> 4, ld_c4 = (tid & 15) << 2;  // 16 rows x 16 float4
+    f32x4_t acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) acc[a][b] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    for (int m0 = m_begin; m0 < m_end; m0 += 16) {
+        const int m = m0 + ld_row;
+        float4 vy = make_float4(0, 0, 0, 0), vx = make_float4(0, 0, 0, 0);
+        if (m < m_end) {
+            if (n_blk + ld_c4 < N) vy = *reinterpret_cast<const float4*>(dY + (size_t)m * N + n_blk + ld_c4);
+            if (k_blk + ld_c4 < K) {
+                const long long xr = x_rows ? (long long)x_rows[m] : (long long)m;
+                if (xr >= 0) vx = *reinterpret_cast<const float4*>(X + (size_t)xr * K + k_blk + ld_c4);
+            }
+        }
+        __syncthreads();
+        *reinterpret_cast<float4*>(&sY[ld_row][ld_c4]) = vy;
+        *reinterpret_cast<float4*>(&sX[ld_row][ld_c4]) = vx;
+        __syncthreads();
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {  // 4 rows of m per MFMA: lane group lg takes row s4*4 + lg
+            const int r = s4 * 4 + (lane >> 4);
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(sX[r][wk * 32 + a * 16 + (lane & 15)],
+                                                                     sY[r][wn * 32 + b * 16 + (lane & 15)], acc[a][b], 0, 0, 0);
+        }
+    }
+    float* o = out + (size_t)split * N * K;
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        const int n = n_blk + wn * 32 + b * 16 + (lane & 15);
+        if (n >= N) continue;
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            const int k0 = k_blk + wk * 32 + a * 16 + (lane >> 4) * 4;
+            if (k0 >= K) continue;
+            *reinterpret_cast<float4*>(o + (size_t)n * K + k0) = make_float4(acc[a][b][0], acc[a][b][1], acc[a][b][2], acc[a][b][3]);
+        }
+    }
+}
+
+__global__ void slab_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ out, int64_t n4, int S) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        float4 a = reinterpret_cast<const float4*>(slabs)[i];
+        for (int s = 1; s < S; ++s) {
+            const float4 b = reinterpret_cast<const float4*>(slabs)[(int64_t)s * n4 + i];
+            a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+        }
+        reinterpret_cast<float4*>(out)[i] = a;
+    }
+}
+
+// column sums of dY (bias gradient): block = 64 columns x 4 row lanes, grid.y row splits, then reduce
+template <typename T>
+__global__ __launch_bounds__(GT) void colsum_kernel(const T* __restrict__ dY, float* __restrict__ part, int M, int N, int rows_per) {
+    __shared__ float s[4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
+    const int m0 = blockIdx.y * rows_per, m1 = min(M, m0 + rows_per);
+    float a = 0.f;
+    if (c < N)
+        for (int m = m0 + rl; m < m1; m += 4) a += Act<T>::ld(dY + (size_t)m * N + c);
+    s[rl][threadIdx.x & 63] = a;
+    __syncthreads();
+    if (rl == 0 && c < N) part[(size_t)blockIdx.y * N + c] = (s[0][threadIdx.x] + s[1][threadIdx.x]) + (s[2][threadIdx.x] + s[3][threadIdx.x]);
+}
+__global__ void colsum_reduce_kernel(const float* __restrict__ part, float* __restrict__ out, int N, int S) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= N) return;
+    float a = 0.f;
+    for (int s = 0; s < S; ++s) a += part[(size_t)s * N + c];
+    out[c] = a;
+}
+
+static void wgrad_plan(int M, int N, int K, int dt, int* S, int* m_per, int* SC, int* rows_per) {
+    const int tile = dt == STAR_BF16 ? WG_TILE : 64;
+    const int step = dt == STAR_BF16 ? WG_BKM : 16;
+    const int tiles = cdiv(N, tile) * cdiv(K, tile);
+    int s = cdiv(1024, tiles);                 // aim for ~4 blocks per CU
+    const int max_s = cdiv(M, 4 * step);       // at least 4 reduction steps per split
+    if (s > max_s) s = max_s;
+    if (s < 1) s = 1;
+    if (s > 64) s = 64;
+    int mp = cdiv(cdiv(M, s), step) * step;
+    s = cdiv(M, mp);
+    *S = s; *m_per = mp;
+    int sc = cdiv(M, 512);
+    if (sc > 64) sc = 64;
+    if (sc < 1) sc = 1;
+    *SC = sc; *rows_per = cdiv(M, sc);
+}
+
+extern "C" int64_t star_gemm_wgrad_ws(int M, int N, int K) {
+    int S, mp, SC, rp, S2, mp2;
+    wgrad_plan(M, N, K, STAR_BF16, &S, &mp, &SC, &rp);
+    wgrad_plan(M, N, K, STAR_F32, &S2, &mp2, &SC, &rp);
+    if (S2 > S) S = S2;
+    return (int64_t)S * N * K + (int64_t)SC * N + 16;
+}
+
+extern "C" int star_gemm_wgrad(const void* dY, const void* X, const int32_t* x_rows, float* dW, float* db, float* ws,
+                               int M, int N, int K, int dt, void* stream) {
+    STAR_CHECK(dY && X && ws && (dW || db), "star_gemm_wgrad: null pointer");
+    STAR_CHECK(M > 0 && N > 0 && K > 0, "star_gemm_wgrad: bad shape M=%d N=%d K=%d", M, N, K);
+    STAR_CHECK(dt == STAR_BF16 || dt == STAR_F32, "star_gemm_wgrad: unknown dtype %d", dt);
+    const int epc = dt == STAR_BF16 ? 8 : 4;
+    STAR_CHECK(N % epc == 0 && K % epc == 0, "star_gemm_wgrad: N=%d and K=%d must be multiples of %d", N, K, epc);
+    hipStream_t s = (hipStream_t)stream;
+    int S, mp, SC, rp;
+    wgrad_plan(M, N, K, dt, &S, &mp, &SC, &rp);
+    if (dW) {
+        float* target = S == 1 ? dW : ws;
+        if (dt == STAR_BF16) {
+            dim3 grid(cdiv(N, WG_TILE) * cdiv(K, WG_TILE), S);
+            hipLaunchKernelGGL(gemm_tn_bf16_kernel, grid, dim3(GT), 4 * WG_BKM * 256, s, (const bf16_t*)dY, (const bf16_t*)X, x_rows, target, M, N, K, mp);
+        } else {
+            dim3 grid(cdiv(N, 64) * cdiv(K, 64), S);
+            hipLaunchKernelGGL(gemm_tn_f32_kernel, grid, dim3(GT), 0, s, (const float*)dY, (const float*)X, x_rows, target, M, N, K, mp);
+        }
+        STAR_LAUNCH_CHECK("star_gemm_wgrad");
+        if (S > 1) {
+            const int64_t n4 = (int64_t)N * K / 4;
+            int gb = cdiv(n4, 256);
+            if (gb > 2048) gb = 2048;
+            hipLaunchKernelGGL(slab_reduce_kernel, dim3(gb), dim3(256), 0, s, ws, dW, n4, S);
+            STAR_LAUNCH_CHECK("star_gemm_wgrad(reduce)");
+        }
+    }
+    if (db) {
+        float* part = ws + (size_t)S * N * K;
+        if (dt == STAR_BF16)
+            hipLaunchKernelGGL(colsum_kernel<bf16_t>, dim3(cdiv(N, 64), SC), dim3(GT), 0, s, (const bf16_t*)dY, part, M, N, rp);
+        else
+            hipLaunchKernelGGL(colsum_kernel<float>, dim3(cdiv(N, 64), SC), dim3(GT), 0, s, (const float*)dY, part, M, N, rp);
+        STAR_LAUNCH_CHECK("star_gemm_wgrad(colsum)");
+        hipLaunchKernelGGL(colsum_reduce_kernel, dim3(cdiv(N, 256)), dim3(256), 0, s, part, db, N, SC);
+        STAR_LAUNCH_CHECK("star_gemm_wgrad(colsum reduce)");
+    }
+    return 0;
+}

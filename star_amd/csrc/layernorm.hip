@@ -1,0 +1,203 @@
+// K2: LayerNorm (eps = 1e-6) forward / backward on the float32 residual stream.
+// Reference: nn.LayerNorm inside timm Block + self.norm / self.decoder_norm
+// (star/models/mae_base.py:279-282,308-312).  HBM-bound: one wave per row, the row lives in registers,
+// 16-byte loads, wavefront reductions; the normalised row leaves in the activation type so that the
+// following MFMA GEMM reads half the bytes.
+#include "common.h"
+
+#define LN_THREADS 256
+#define LN_MAXV 8          // float4 per lane: D <= 64*4*8 = 2048
+#define LN_BWD_BLOCKS 512  // partial dgamma/dbeta rows
+
+template <typename T, int NV>
+__global__ __launch_bounds__(LN_THREADS) void ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, T* __restrict__ y,
+                                                            float* __restrict__ mean, float* __restrict__ rstd, int M,
+                                                            int D, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * (LN_THREADS / 64) + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const int nv = D >> 2;  // float4 per row
+    const float* xr = x + (size_t)row * D;
+    float v[NV][4];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = lane + i * 64;
+        if (c < nv) {
+            ld4(xr + c * 4, v[i]);
+            s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+        }
+    }
+    const float mu = wave_sum(s) / (float)D;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = lane + i * 64;
+        if (c < nv) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float d = v[i][k] - mu;
+                q += d * d;
+            }
+        }
+    }
+    const float rs = rsqrtf(wave_sum(q) / (float)D + eps);
+    if (lane == 0) {
+        if (mean) mean[row] = mu;
+        if (rstd) rstd[row] = rs;
+    }
+    T* yr = y + (size_t)row * D;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = lane + i * 64;
+        if (c < nv) {
+            float g[4], b[4], o[4];
+            ld4(gamma + c * 4, g);
+            ld4(beta + c * 4, b);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) o[k] = (v[i][k] - mu) * rs * g[k] + b[k];
+            st4(yr + c * 4, o);
+        }
+    }
+}
+
+// Backward.  Each wave walks rows with a grid stride and keeps its dgamma/dbeta partials in registers;
+// the block folds its 4 waves through LDS and writes one partial row; a second kernel sums the partial
+// rows in a fixed order (deterministic).
+template <typename T, int NV>
+__global__ __launch_bounds__(LN_THREADS) void ln_bwd_kernel(const T* __restrict__ dy, const float* __restrict__ x,
+                                                            const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                            const float* __restrict__ rstd, const float* g_in,
+                                                            float* g_out, T* __restrict__ g_lp,
+                                                            float* __restrict__ ws, int M, int D) {
+    extern __shared__ float s_part[];  // [4 waves][2][D]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nv = D >> 2;
+    float pg[NV][4], pb[NV][4], gm[NV][4];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = lane + i * 64;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) pg[i][k] = pb[i][k] = 0.f;
+        if (c < nv) ld4(gamma + c * 4, gm[i]);
+    }
+    for (int row = blockIdx.x * 4 + wave; row < M; row += gridDim.x * 4) {
+        const float mu = mean[row], rs = rstd[row];
+        float xh[NV][4], dg[NV][4];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = lane + i * 64;
+            if (c < nv) {
+                float xv[4], dv[4];
+                ld4(x + (size_t)row * D + c * 4, xv);
+                ld4(dy + (size_t)row * D + c * 4, dv);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    xh[i][k] = (xv[k] - mu) * rs;
+                    dg[i][k] = dv[k] * gm[i][k];
+                    s1 += dg[i][k];
+                    s2 += dg[i][k] * xh[i][k];
+                    pg[i][k] += dv[k] * xh[i][k];
+                    pb[i][k] += dv[k];
+                }
+            }
+        }
+        const float m1 = wave_sum(s1) / (float)D, m2 = wave_sum(s2) / (float)D;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = lane + i * 64;
+            if (c < nv) {
+                float o[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) o[k] = rs * (dg[i][k] - m1 - xh[i][k] * m2);
+                if (g_in) {
+                    float gi[4];
+                    ld4(g_in + (size_t)row * D + c * 4, gi);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) o[k] += gi[k];
+                }
+                if (g_out) st4(g_out + (size_t)row * D + c * 4, o);
+                if (g_lp) st4(g_lp + (size_t)row * D + c * 4, o);
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = lane + i * 64;
+        if (c < nv) {
+            st4(s_part + (size_t)(wave * 2 + 0) * D + c * 4, pg[i]);
+            st4(s_part + (size_t)(wave * 2 + 1) * D + c * 4, pb[i]);
+        }
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < 2 * D; e += LN_THREADS) {
+        const int which = e / D, c = e - which * D;
+        float a = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) a += s_part[(size_t)(w * 2 + which) * D + c];
+        ws[(size_t)blockIdx.x * 2 * D + e] = a;
+    }
+}
+
+__global__ void ln_bwd_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                     int nblocks, int D) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= 2 * D) return;
+    float a = 0.f;
+    for (int b = 0; b < nblocks; ++b) a += ws[(size_t)b * 2 * D + e];
+    if (e < D) {
+        if (dgamma) dgamma[e] = a;
+    } else if (dbeta) {
+        dbeta[e - D] = a;
+    }
+}
+
+extern "C" int star_layernorm_fwd(const float* x, const float* gamma, const float* beta, void* y, float* mean,
+                                  float* rstd, int M, int D, float eps, int dt, void* stream) {
+    STAR_CHECK(x && gamma && beta && y, "star_layernorm_fwd: null pointer");
+    STAR_CHECK(M >= 0 && D >= 4 && D % 4 == 0 && D <= 64 * 4 * LN_MAXV, "star_layernorm_fwd: D=%d must be a multiple of 4, <= %d", D, 64 * 4 * LN_MAXV);
+    if (M == 0) return 0;
+    dim3 grid(cdiv(M, LN_THREADS / 64));
+#define LN_FWD(NV)                                                                                                  \
+    do {                                                                                                            \
+        if (dt == STAR_BF16)                                                                                        \
+            hipLaunchKernelGGL((ln_fwd_kernel<bf16_t, NV>), grid, dim3(LN_THREADS), 0, (hipStream_t)stream, x, gamma, \
+                               beta, (bf16_t*)y, mean, rstd, M, D, eps);                                            \
+        else                                                                                                        \
+            hipLaunchKernelGGL((ln_fwd_kernel<float, NV>), grid, dim3(LN_THREADS), 0, (hipStream_t)stream, x, gamma,  \
+                               beta, (float*)y, mean, rstd, M, D, eps);                                             \
+    } while (0)
+    const int nvec = (D / 4 + 63) / 64;
+    if (nvec <= 1) LN_FWD(1); else if (nvec == 2) LN_FWD(2); else if (nvec == 3) LN_FWD(3); else if (nvec == 4) LN_FWD(4); else LN_FWD(LN_MAXV);
+    STAR_LAUNCH_CHECK("star_layernorm_fwd");
+    return 0;
+}
+
+extern "C" int64_t star_layernorm_bwd_ws(int D) { return (int64_t)LN_BWD_BLOCKS * 2 * D; }
+
+extern "C" int star_layernorm_bwd(const void* dy, const float* x, const float* gamma, const float* mean,
+                                  const float* rstd, const float* g_in, float* g_out, void* g_out_lp, float* dgamma,
+                                  float* dbeta, float* ws, int M, int D, int dt, void* stream) {
+    STAR_CHECK(dy && x && gamma && mean && rstd && ws, "star_layernorm_bwd: null pointer");
+    STAR_CHECK(M > 0 && D >= 4 && D % 4 == 0 && D <= 64 * 4 * LN_MAXV, "star_layernorm_bwd: bad M=%d D=%d", M, D);
+    int nb = cdiv(M, 4);
+    if (nb > LN_BWD_BLOCKS) nb = LN_BWD_BLOCKS;
+    const size_t lds = (size_t)8 * D * sizeof(float);
+#define LN_BWD(NV)                                                                                                   \
+    do {                                                                                                             \
+        if (dt == STAR_BF16)                                                                                         \
+            hipLaunchKernelGGL((ln_bwd_kernel<bf16_t, NV>), dim3(nb), dim3(LN_THREADS), lds, (hipStream_t)stream,      \
+                               (const bf16_t*)dy, x, gamma, mean, rstd, g_in, g_out, (bf16_t*)g_out_lp, ws, M, D);   \
+        else                                                                                                         \
+            hipLaunchKernelGGL((ln_bwd_kernel<float, NV>), dim3(nb), dim3(LN_THREADS), lds, (hipStream_t)stream,       \
+                               (const float*)dy, x, gamma, mean, rstd, g_in, g_out, (float*)g_out_lp, ws, M, D);     \
+    } while (0)
+    const int nvec = (D / 4 + 63) / 64;
+    if (nvec <= 1) LN_BWD(1); else if (nvec == 2) LN_BWD(2); else if (nvec == 3) LN_BWD(3); else if (nvec == 4) LN_BWD(4); else LN_BWD(LN_MAXV);
+    STAR_LAUNCH_CHECK("star_layernorm_bwd");
+    hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3(cdiv(2 * D, 256)), dim3(256), 0, (hipStream_t)stream, ws, dgamma, dbeta, nb, D);
+    STAR_LAUNCH_CHECK("star_layernorm_bwd(reduce)");
+    return 0;
+}

@@ -1,0 +1,257 @@
+"""Tensor-level wrappers over the C ABI (one per kernel group).  PyTorch only allocates and hands over
+device pointers here; all arithmetic happens in libstar_hip.so."""
+import ctypes as C
+import math
+
+import numpy as np
+import torch
+
+from . import _lib as L
+from ._lib import ACT_DGELU, ACT_DRELU, ACT_GELU, ACT_NONE, ACT_RELU, BF16, F32, p  # noqa: F401
+
+
+def _cuda(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("star_amd ops need device tensors (got a CPU tensor)")
+
+
+# ---------------------------------------------------------------------------------------------------
+def warp_thetas(trans_matrices):
+    """Host part of feature_transformation (reference star/models/mae_base.py:593-606): the rotation
+    block and the normalised translation of every (scene, ego, neighbour) pose, formed in the SOURCE
+    dtype of `trans_matrices` and only then cast to float32.  Returns float32 [B, A, A, 8] (CPU)."""
+    t = trans_matrices.detach().cpu() if isinstance(trans_matrices, torch.Tensor) else torch.as_tensor(np.asarray(trans_matrices))
+    out = torch.zeros(t.shape[:3] + (8,), dtype=torch.float32)
+    out[..., 0] = t[..., 0, 0].to(torch.float32)
+    out[..., 1] = t[..., 0, 1].to(torch.float32)
+    out[..., 2] = t[..., 1, 0].to(torch.float32)
+    out[..., 3] = t[..., 1, 1].to(torch.float32)
+    out[..., 4] = ((4 * t[..., 0, 3]) / 128).to(torch.float32)
+    out[..., 5] = (-(4 * t[..., 1, 3]) / 128).to(torch.float32)
+    return out
+
+
+def warp_fuse(pred_u8, theta, num_agent, batch, ego=None):
+    """K10.  pred_u8 uint8 [A*B,C,H,W]; theta float32 [B,A,A,8] on the device; num_agent int [B,A] on
+    the device; ego optional float32 [A*B,C,H,W] with any strides.  -> float32 [A*B,C,H,W]."""
+    _cuda(pred_u8, theta, num_agent, ego)
+    ab, c, h, w = pred_u8.shape
+    assert ab % batch == 0, (pred_u8.shape, batch)
+    a = ab // batch
+    assert pred_u8.dtype == torch.uint8 and pred_u8.is_contiguous()
+    assert theta.dtype == torch.float32 and theta.is_contiguous() and tuple(theta.shape) == (batch, a, a, 8)
+    assert num_agent.dtype in (torch.int32, torch.int64) and num_agent.is_contiguous() and tuple(num_agent.shape) == (batch, a)
+    out = torch.empty(ab, c, h, w, dtype=torch.float32, device=pred_u8.device)
+    es = (0, 0, 0, 0)
+    if ego is not None:
+        assert ego.dtype == torch.float32 and tuple(ego.shape) == (ab, c, h, w)
+        es = ego.stride()
+    L.check(L.lib().star_warp_fuse(p(pred_u8), p(ego), es[0], es[1], es[2], es[3], p(theta), p(num_agent),
+                                   int(num_agent.dtype == torch.int64), p(out), batch, a, c, h, w, L.stream()))
+    return out
+
+
+def mask_sort(noise):
+    """K5.  noise float32 [R, L] -> (ids_shuffle, ids_restore) int64 [R, L]."""
+    _cuda(noise)
+    assert noise.dtype == torch.float32 and noise.dim() == 2
+    noise = noise.contiguous()
+    r, l = noise.shape
+    ids_shuffle = torch.empty(r, l, dtype=torch.int64, device=noise.device)
+    ids_restore = torch.empty(r, l, dtype=torch.int64, device=noise.device)
+    L.check(L.lib().star_mask_sort(p(noise), p(ids_shuffle), p(ids_restore), r, l, L.stream()))
+    return ids_shuffle, ids_restore
+
+
+def build_rowmaps(ids_shuffle, ids_restore, ba, t, l, keep, random_mode, single, want_mask=True):
+    dev = ids_shuffle.device
+    rows = ba * t * keep
+    src = torch.empty(rows, dtype=torch.int32, device=dev)
+    dst = torch.empty(rows, dtype=torch.int32, device=dev)
+    mask = torch.empty((ba * t, l) if random_mode else (ba, t, l), dtype=torch.float32, device=dev) if want_mask else None
+    fill = torch.empty(ba * l, dtype=torch.int32, device=dev)
+    L.check(L.lib().star_build_rowmaps(p(ids_shuffle), p(ids_restore), p(src), p(dst), p(mask), p(fill), ba, t, l,
+                                       keep, int(random_mode), int(single), L.stream()))
+    return src, dst, mask, fill
+
+
+# ---------------------------------------------------------------------------------------------------
+def layernorm_fwd(x, gamma, beta, eps, dt, want_stats=True):
+    _cuda(x, gamma, beta)
+    m, d = x.shape
+    assert x.dtype == torch.float32 and x.is_contiguous()
+    y = torch.empty(m, d, dtype=L.torch_dtype(dt), device=x.device)
+    mean = torch.empty(m, dtype=torch.float32, device=x.device) if want_stats else None
+    rstd = torch.empty(m, dtype=torch.float32, device=x.device) if want_stats else None
+    L.check(L.lib().star_layernorm_fwd(p(x), p(gamma), p(beta), p(y), p(mean), p(rstd), m, d, float(eps), dt, L.stream()))
+    return y, mean, rstd
+
+
+def layernorm_bwd(dy, x, gamma, mean, rstd, g_in=None, want_lp=True, g_out=None):
+    """-> (g_out float32 [M,D] = g_in + dx, g_lp copy in dy's dtype or None, dgamma, dbeta)."""
+    m, d = x.shape
+    dt = L.dt_of(dy)
+    assert dy.is_contiguous() and x.is_contiguous()
+    if g_out is None:
+        g_out = torch.empty(m, d, dtype=torch.float32, device=x.device)
+    g_lp = torch.empty(m, d, dtype=dy.dtype, device=x.device) if want_lp else None
+    dgamma = torch.empty(d, dtype=torch.float32, device=x.device)
+    dbeta = torch.empty(d, dtype=torch.float32, device=x.device)
+    ws = torch.empty(L.lib().star_layernorm_bwd_ws(d), dtype=torch.float32, device=x.device)
+    L.check(L.lib().star_layernorm_bwd(p(dy), p(x), p(gamma), p(mean), p(rstd), p(g_in), p(g_out), p(g_lp), p(dgamma),
+                                       p(dbeta), p(ws), m, d, dt, L.stream()))
+    return g_out, g_lp, dgamma, dbeta
+
+
+# ---------------------------------------------------------------------------------------------------
+def gemm(a, w, m=None, bias=None, act=ACT_NONE, res=None, res_mod=0, res2=None, res2_div=0, res2_mod=0, aux=None,
+         a_rows=None, c_rows=None, out_rows=None, want_pre=False, want_lp=True, want_f32=False, out_f32=None, out_lp=None):
+    """C = epilogue(A[a_rows] @ W^T).  a [*, K], w [N, K] same dtype (bf16 or f32).
+    Returns (out_lp, out_f32, pre) -- entries not requested are None."""
+    _cuda(a, w)
+    dt = L.dt_of(a)
+    assert w.dtype == a.dtype and a.is_contiguous() and w.is_contiguous()
+    k = a.shape[-1]
+    n = w.shape[0]
+    assert w.shape[1] == k
+    if m is None:
+        m = a_rows.numel() if a_rows is not None else a.shape[0]
+    rows_out = out_rows if out_rows is not None else m
+    dev = a.device
+    if want_lp and out_lp is None:
+        out_lp = (torch.zeros if c_rows is not None else torch.empty)(rows_out, n, dtype=a.dtype, device=dev)
+    if want_f32 and out_f32 is None:
+        out_f32 = (torch.zeros if c_rows is not None else torch.empty)(rows_out, n, dtype=torch.float32, device=dev)
+    pre = torch.empty(rows_out, n, dtype=a.dtype, device=dev) if want_pre else None
+    g = L.StarGemm(p(a), p(w), p(a_rows), p(c_rows), p(bias), p(res), res_mod, p(res2), res2_div, res2_mod, p(aux), act,
+                   p(pre), p(out_lp), p(out_f32), m, n, k, dt)
+    L.check(L.lib().star_gemm(C.byref(g), L.stream()))
+    return out_lp, out_f32, pre
+
+
+def gemm_wgrad(dy, x, x_rows=None, want_bias=True, want_weight=True):
+    """dW [N,K] = dY^T X[x_rows], db [N] = colsum(dY)."""
+    _cuda(dy, x)
+    dt = L.dt_of(dy)
+    assert x.dtype == dy.dtype and dy.is_contiguous() and x.is_contiguous()
+    m, n = dy.shape
+    k = x.shape[1]
+    dev = dy.device
+    dw = torch.empty(n, k, dtype=torch.float32, device=dev) if want_weight else None
+    db = torch.empty(n, dtype=torch.float32, device=dev) if want_bias else None
+    ws = torch.empty(L.lib().star_gemm_wgrad_ws(m, n, k), dtype=torch.float32, device=dev)
+    L.check(L.lib().star_gemm_wgrad(p(dy), p(x), p(x_rows), p(dw), p(db), p(ws), m, n, k, dt, L.stream()))
+    return dw, db
+
+
+# ---------------------------------------------------------------------------------------------------
+def attn_fwd(qkv, nb, l, h, hd):
+    """qkv [NB*L, 3*H*hd] -> (out [NB*L, H*hd], lse float32 [NB, H, L])."""
+    _cuda(qkv)
+    dt = L.dt_of(qkv)
+    assert qkv.is_contiguous() and qkv.numel() == nb * l * 3 * h * hd
+    out = torch.empty(nb * l, h * hd, dtype=qkv.dtype, device=qkv.device)
+    lse = torch.empty(nb, h, l, dtype=torch.float32, device=qkv.device)
+    L.check(L.lib().star_attn_fwd(p(qkv), p(out), p(lse), nb, l, h, hd, dt, L.stream()))
+    return out, lse
+
+
+def attn_bwd(qkv, out, dout, lse, nb, l, h, hd):
+    dt = L.dt_of(qkv)
+    assert qkv.is_contiguous() and out.is_contiguous() and dout.is_contiguous() and dout.dtype == qkv.dtype
+    dqkv = torch.empty_like(qkv)
+    delta = torch.empty(nb, h, l, dtype=torch.float32, device=qkv.device)
+    L.check(L.lib().star_attn_bwd(p(qkv), p(out), p(dout), p(lse), p(delta), p(dqkv), nb, l, h, hd, dt, L.stream()))
+    return dqkv
+
+
+# ---------------------------------------------------------------------------------------------------
+def patchify(img1, img_next, t, patch, dt, channels_last_order=False):
+    """K1.  img1 float32 [BA,C,H,W] (any strides), img_next [BA,T-1,C,H,W] -> [BA*T*L, C*p*p]."""
+    _cuda(img1)
+    ba, c, h, w = img1.shape
+    assert img1.dtype == torch.float32
+    ln = (h // patch) * (w // patch)
+    out = torch.empty(ba * t * ln, c * patch * patch, dtype=L.torch_dtype(dt), device=img1.device)
+    sn = None
+    if t > 1:
+        assert img_next.dtype == torch.float32 and tuple(img_next.shape) == (ba, t - 1, c, h, w)
+        sn = L.strides(img_next)
+    L.check(L.lib().star_patchify(p(img1), L.strides(img1), p(img_next) if t > 1 else None, sn, p(out), ba, t, c, h, w,
+                                  patch, dt | (256 if channels_last_order else 0), L.stream()))
+    return out
+
+
+def ce_argmax(logits, target, patch, dt, want_pred=False, want_dlogits=True, want_loss=True):
+    """K9.  logits float32 [BA*L, 2*C*p*p] (patch layout), target float32 [BA,C,H,W] any strides.
+    -> dict(loss float32[1], ind64, ind8, pred, dlogits)."""
+    _cuda(logits, target)
+    ba, c, h, w = target.shape
+    assert logits.dtype == torch.float32 and logits.is_contiguous() and target.dtype == torch.float32
+    dev = logits.device
+    ind64 = torch.empty(ba, c, h, w, dtype=torch.int64, device=dev)
+    ind8 = torch.empty(ba, c, h, w, dtype=torch.uint8, device=dev)
+    pred = torch.empty(ba, 2, c, h, w, dtype=torch.float32, device=dev) if want_pred else None
+    dlog = torch.empty(logits.shape, dtype=L.torch_dtype(dt), device=dev) if want_dlogits else None
+    nb = L.lib().star_ce_nblocks(ba, c, h, w)
+    part = torch.empty(nb, dtype=torch.float32, device=dev) if want_loss else None
+    loss = torch.empty(1, dtype=torch.float32, device=dev) if want_loss else None
+    L.check(L.lib().star_ce_argmax(p(logits), p(target), L.strides(target), p(ind64), p(ind8), p(pred), p(dlog), p(part),
+                                   ba, c, h, w, patch, dt, L.stream()))
+    if want_loss:
+        L.check(L.lib().star_ce_finish(p(part), nb, ba * c * h * w, p(loss), L.stream()))
+    return dict(loss=loss, ind64=ind64, ind8=ind8, pred=pred, dlogits=dlog)
+
+
+def fill_rows(x, fill, mask_token, temp0, pos, ba, l):
+    d = x.shape[-1]
+    L.check(L.lib().star_fill_rows(p(x), p(fill), p(mask_token), p(temp0), p(pos), ba, l, d, L.stream()))
+
+
+def transpose_rows(src, pos, ba, l, d):
+    dst = torch.empty_like(src)
+    L.check(L.lib().star_transpose_rows(p(src), p(dst), p(pos), ba, l, d, L.stream()))
+    return dst
+
+
+def transpose_rows_bwd(gdst, ba, l, d):
+    gsrc = torch.empty_like(gdst)
+    L.check(L.lib().star_transpose_rows_bwd(p(gdst), p(gsrc), ba, l, d, L.stream()))
+    return gsrc
+
+
+def cast(src, dt):
+    assert src.dtype == torch.float32 and src.is_contiguous()
+    dst = torch.empty(src.shape, dtype=L.torch_dtype(dt), device=src.device)
+    L.check(L.lib().star_cast(p(src), p(dst), src.numel(), dt, L.stream()))
+    return dst
+
+
+def cast_back(src):
+    dst = torch.empty(src.shape, dtype=torch.float32, device=src.device)
+    L.check(L.lib().star_cast_back(p(src), p(dst), src.numel(), L.dt_of(src), L.stream()))
+    return dst
+
+
+def adamw(pflat, gflat, m, v, wd_mask, lr, beta1, beta2, eps, wd, step, gscale=None):
+    L.check(L.lib().star_adamw(p(pflat), p(gflat), p(m), p(v), p(wd_mask), p(gscale), pflat.numel(), float(lr), float(beta1),
+                               float(beta2), float(eps), float(wd), int(step), L.stream()))
+
+
+def sumsq(x):
+    ws = torch.empty(1024, dtype=torch.float32, device=x.device)
+    out = torch.empty(1, dtype=torch.float32, device=x.device)
+    L.check(L.lib().star_sumsq(p(x), x.numel(), p(ws), p(out), L.stream()))
+    return out
+
+
+def iou_confusion(pred, target, conf=None):
+    """K11.  pred/target float32 [N,Z,H,W] -> int64 [3,2,2] confusion counts (added into `conf`)."""
+    _cuda(pred, target)
+    pred, target = pred.contiguous(), target.contiguous()
+    n, z, h, w = pred.shape
+    if conf is None:
+        conf = torch.zeros(3, 2, 2, dtype=torch.int64, device=pred.device)
+    L.check(L.lib().star_iou_confusion(p(pred), p(target), p(conf), n, z, h, w, L.stream()))
+    return conf

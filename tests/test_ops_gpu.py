@@ -1,0 +1,333 @@
+"""Per-kernel parity tests through the C ABI (run on the MI355X box: pytest -m gpu).
+
+Integer / index / occupancy-map work is checked bit-exact against the oracle and the committed golden
+vectors; floating-point kernels against the same op evaluated by PyTorch in float32/float64 with the
+tolerance written next to each check."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from golden_util import GOLD, unpack
+
+pytestmark = pytest.mark.gpu
+
+if torch.cuda.is_available():
+    from oracle import star_oracle as O
+    from star_amd import ops
+    from star_amd._lib import ACT_DGELU, ACT_DRELU, ACT_GELU, ACT_NONE, ACT_RELU, BF16, F32
+
+DEV = "cuda"
+
+
+def _tol(dt):
+    # bf16 storage: 8 significant bits in every stored operand/result; fp32 path: accumulation order only
+    return dict(rtol=2e-2, atol=2e-2) if dt == 0 else dict(rtol=2e-5, atol=2e-5)
+
+
+# ------------------------------------------------------------------------------------------------
+def test_warp_fuse_golden_full_resolution_bit_exact():
+    z = np.load(GOLD + "/warp_full256.npz")
+    ind = unpack(z["ind_bits"], z["shape"], np.uint8)
+    gt = unpack(z["gt_bits"], z["shape"])
+    trans, na = z["trans"], z["num_agent"]
+    B = trans.shape[0]
+    pred = torch.from_numpy(ind).to(DEV)
+    nad = torch.from_numpy(na).to(DEV)
+    for tr, key in ((trans, "late_bits"), (trans.astype(np.float32), "late32_bits")):
+        theta = ops.warp_thetas(torch.from_numpy(tr)).to(DEV)
+        out = ops.warp_fuse(pred, theta, nad, B)
+        assert np.array_equal(out.cpu().numpy(), unpack(z[key], z["shape"])), key
+    theta = ops.warp_thetas(torch.from_numpy(trans)).to(DEV)
+    # ego = ground truth input, handed over as NHWC memory viewed NCHW (what CoModule does)
+    ego = torch.from_numpy(gt).to(DEV).permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)
+    out = ops.warp_fuse(pred, theta, nad.int(), B, ego=ego)
+    assert np.array_equal(out.cpu().numpy(), unpack(z["ego_bits"], z["shape"]))
+
+
+def test_warp_fuse_random_poses_vs_oracle():
+    rng = np.random.RandomState(3)
+    B, A, C, S = 2, 4, 13, 64
+    ind = (rng.rand(A * B, C, S, S) < 0.1).astype(np.uint8)
+    trans = np.zeros((B, A, A, 4, 4))
+    for b in range(B):
+        for i in range(A):
+            for j in range(A):
+                yaw, tx, ty = rng.uniform(-math.pi, math.pi), rng.uniform(-40, 40), rng.uniform(-40, 40)
+                trans[b, i, j] = [[math.cos(yaw), -math.sin(yaw), 0, tx], [math.sin(yaw), math.cos(yaw), 0, ty], [0, 0, 1, 0], [0, 0, 0, 1]]
+    na = np.array([[4] * A, [2] * A])
+    want = O.late_fusion(ind.astype(np.float32), trans, na, B)
+    out = ops.warp_fuse(torch.from_numpy(ind).to(DEV), ops.warp_thetas(torch.from_numpy(trans)).to(DEV), torch.from_numpy(na).to(DEV), B)
+    assert np.array_equal(out.cpu().numpy(), want)
+
+
+@pytest.mark.parametrize("R,L", [(5, 16), (7, 1024), (3, 342), (2, 4096), (40, 1024)])
+def test_mask_sort_bit_exact(R, L):
+    g = torch.Generator().manual_seed(R * 1000 + L)
+    noise = torch.rand(R, L, generator=g)
+    noise[0, : L // 2] = noise[0, L // 2: 2 * (L // 2)]     # ties: stable order must win
+    s_ref, r_ref = O.shuffle_ids(noise)
+    s, r = ops.mask_sort(noise.to(DEV))
+    assert torch.equal(s.cpu(), s_ref) and torch.equal(r.cpu(), r_ref)
+
+
+@pytest.mark.parametrize("T,random_mode,single", [(1, 0, 0), (2, 0, 0), (3, 0, 0), (3, 0, 1), (3, 1, 0), (3, 1, 1), (2, 1, 0)])
+def test_rowmaps_reproduce_masking_and_unmasking(T, random_mode, single):
+    """gather by src_row == the reference masking; scatter by dst_row (+fill) == the reference un-masking."""
+    BA, L, D = 3, 16, 8
+    g = torch.Generator().manual_seed(11 + T)
+    x = torch.randn(BA * T, L, D, generator=g)
+    ratio = 0.75
+    if random_mode:
+        noise = torch.rand(BA * T, L, generator=g)
+        xm, mask_ref, ids_restore = O.random_masking(x, ratio, noise)
+        keep = int(L * (1 - ratio))
+    else:
+        noise = torch.rand(BA, L, generator=g)
+        xm, mask_ref, ids_restore = O.complement_masking(x, T, noise)
+        keep = math.ceil(L * (1 - (1.0 - 1.0 / T)))
+    ids_s, ids_r = ops.mask_sort(noise.to(DEV))
+    assert torch.equal(ids_r.cpu(), ids_restore)
+    src, dst, mask, fill = ops.build_rowmaps(ids_s, ids_r, BA, T, L, keep, random_mode, single)
+    src, dst, mask, fill = src.cpu().long(), dst.cpu().long(), mask.cpu(), fill.cpu()
+    assert torch.equal(mask, mask_ref)
+    flat = torch.cat([x.reshape(-1, D), torch.zeros(1, D)])
+    assert torch.equal(flat[src].reshape(BA * T, keep, D), xm)
+    # un-masking: rows carry their timestamp's embedding; uncovered rows take the mask token
+    temp = torch.randn(1, T, 1, D, generator=g)
+    tok = torch.randn(1, 1, D, generator=g)
+    if random_mode:
+        want = O.random_unmasking(xm, mask_ref, ids_restore, T, temp, tok, False, bool(single)).permute(0, 2, 1)
+    else:
+        want = O.complement_unmasking(xm, ids_restore, T, temp, tok, False, bool(single))
+    rows = xm.reshape(BA, T, keep, D) + temp
+    got = torch.full((BA * L + 1, D), float("nan"))
+    got[dst] = rows.reshape(-1, D)          # dst == -1 lands in the spare last row
+    got = got[:-1]
+    fillv = tok.reshape(D) + (temp[0, 0, 0] if random_mode else 0)
+    got[fill.bool()] = fillv
+    assert torch.equal(got.reshape(BA, L, D), want)
+
+
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dt", [0, 1])
+@pytest.mark.parametrize("M,D", [(80, 32), (1000, 384), (515, 256), (64, 768), (33, 1024)])
+def test_layernorm_fwd_bwd(dt, M, D):
+    g = torch.Generator().manual_seed(M + D)
+    x = (torch.randn(M, D, generator=g) * 2 + 0.5).to(DEV)
+    gamma = (1 + 0.1 * torch.randn(D, generator=g)).to(DEV)
+    beta = (0.1 * torch.randn(D, generator=g)).to(DEV)
+    y, mean, rstd = ops.layernorm_fwd(x, gamma, beta, 1e-6, dt)
+    xr = x.double().requires_grad_(True)
+    gr, br = gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
+    yr = torch.nn.functional.layer_norm(xr, (D,), gr, br, 1e-6)
+    torch.testing.assert_close(y.double(), yr.detach(), **_tol(dt))
+    torch.testing.assert_close(mean.double(), xr.detach().mean(1), rtol=1e-5, atol=1e-5)
+    dy = torch.randn(M, D, generator=g).to(DEV).to(y.dtype)
+    g_in = torch.randn(M, D, generator=g).to(DEV)
+    yr.backward(dy.double())
+    g_out, g_lp, dgamma, dbeta = ops.layernorm_bwd(dy, x, gamma, mean, rstd, g_in=g_in)
+    torch.testing.assert_close(g_out.double(), g_in.double() + xr.grad, rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(g_lp.double(), g_out.double(), **_tol(dt))
+    torch.testing.assert_close(dgamma.double(), gr.grad, rtol=1e-4, atol=1e-3)
+    torch.testing.assert_close(dbeta.double(), br.grad, rtol=1e-4, atol=1e-3)
+
+
+def _rand_lp(shape, g, dt, scale=1.0):
+    t = (torch.randn(*shape, generator=g) * scale).to(DEV)
+    return t.to(torch.bfloat16) if dt == 0 else t
+
+
+@pytest.mark.parametrize("dt", [0, 1])
+@pytest.mark.parametrize("M,N,K", [(80, 96, 32), (300, 384, 384), (1024, 1152, 384), (257, 32, 384), (130, 1664, 256), (64, 256, 1536), (100, 64, 832), (16, 48, 64)])
+def test_gemm_plain(dt, M, N, K):
+    g = torch.Generator().manual_seed(M * 7 + N * 3 + K)
+    a, w = _rand_lp((M, K), g, dt), _rand_lp((N, K), g, dt, K ** -0.5)
+    bias = torch.randn(N, generator=g).to(DEV)
+    lp, f32, _ = ops.gemm(a, w, bias=bias, want_f32=True)
+    ref = a.double() @ w.double().t() + bias.double()
+    torch.testing.assert_close(f32.double(), ref, rtol=1e-4, atol=1e-4 if dt else 2e-3)
+    torch.testing.assert_close(lp.double(), ref, **_tol(dt))
+
+
+def test_gemm_asymmetric_identity():
+    """A = I against an asymmetric W catches a transposed fragment or output map."""
+    for dt in (0, 1):
+        K = 64
+        a = torch.eye(K, device=DEV).to(torch.bfloat16 if dt == 0 else torch.float32)
+        w = (torch.arange(128 * K, device=DEV).reshape(128, K) % 61).float().to(a.dtype)
+        _, f32, _ = ops.gemm(a, w, want_f32=True, want_lp=False)
+        assert torch.equal(f32, w.float().t())
+
+
+@pytest.mark.parametrize("dt", [0, 1])
+def test_gemm_epilogues(dt):
+    g = torch.Generator().manual_seed(5)
+    M, N, K, L = 200, 128, 64, 50
+    a, w = _rand_lp((M, K), g, dt), _rand_lp((N, K), g, dt, K ** -0.5)
+    bias = torch.randn(N, generator=g).to(DEV)
+    base = a.double() @ w.double().t() + bias.double()
+    # GELU with pre-activation copy
+    lp, _, pre = ops.gemm(a, w, bias=bias, act=ACT_GELU, want_pre=True)
+    torch.testing.assert_close(pre.double(), base, **_tol(dt))
+    torch.testing.assert_close(lp.double(), torch.nn.functional.gelu(base), **_tol(dt))
+    # ReLU, float32 + low-precision outputs
+    lp, f32, _ = ops.gemm(a, w, bias=bias, act=ACT_RELU, want_f32=True)
+    torch.testing.assert_close(f32.double(), base.clamp_min(0), rtol=1e-4, atol=2e-3)
+    # residual in place (x += A W^T + b)
+    x = torch.randn(M, N, generator=g).to(DEV)
+    x0 = x.clone()
+    ops.gemm(a, w, bias=bias, res=x, out_f32=x, want_lp=False)
+    torch.testing.assert_close(x.double(), x0.double() + base, rtol=1e-4, atol=2e-3)
+    # periodic table (pos embed) + per-timestamp table (temp embed)
+    pos = torch.randn(L, N, generator=g).to(DEV)
+    temp = torch.randn(4, N, generator=g).to(DEV)
+    _, f32, _ = ops.gemm(a, w, bias=bias, res=pos, res_mod=L, res2=temp, res2_div=25, res2_mod=4, want_f32=True, want_lp=False)
+    rows = torch.arange(M, device=DEV)
+    ref = base + pos.double()[rows % L] + temp.double()[(rows // 25) % 4]
+    torch.testing.assert_close(f32.double(), ref, rtol=1e-4, atol=2e-3)
+    # gathered A rows (-1 = zero row) and scattered C rows (-1 = dropped)
+    a_rows = torch.randint(-1, M, (150,), generator=g).int().to(DEV)
+    perm = torch.randperm(180, generator=g)[:150].int()
+    perm[::7] = -1
+    c_rows = perm.to(DEV)
+    _, f32, _ = ops.gemm(a, w, bias=bias, a_rows=a_rows, c_rows=c_rows, out_rows=180, res=pos, res_mod=L, want_f32=True, want_lp=False)
+    az = torch.cat([a.double(), torch.zeros(1, K, device=DEV, dtype=torch.double)])
+    full = az[a_rows.long()] @ w.double().t() + bias.double()
+    ref = torch.zeros(180, N, device=DEV, dtype=torch.double)
+    ok = c_rows >= 0
+    dest = c_rows[ok].long()
+    ref[dest] = full[ok] + pos.double()[dest % L]
+    torch.testing.assert_close(f32.double(), ref, rtol=1e-4, atol=2e-3)
+    # activation gradients
+    u = _rand_lp((M, N), g, dt)
+    lp, _, _ = ops.gemm(a, w, act=ACT_DGELU, aux=u)
+    ud = u.double().requires_grad_(True)
+    torch.nn.functional.gelu(ud).sum().backward()
+    torch.testing.assert_close(lp.double(), (a.double() @ w.double().t()) * ud.grad, **_tol(dt))
+    lp, _, _ = ops.gemm(a, w, act=ACT_DRELU, aux=u)
+    torch.testing.assert_close(lp.double(), (a.double() @ w.double().t()) * (u.double() > 0), **_tol(dt))
+
+
+@pytest.mark.parametrize("dt", [0, 1])
+@pytest.mark.parametrize("M,N,K", [(80, 96, 32), (5000, 384, 1152), (1024, 1536, 384), (700, 32, 384), (333, 1664, 256), (40960, 384, 384)])
+def test_gemm_wgrad(dt, M, N, K):
+    g = torch.Generator().manual_seed(M + N + K)
+    dy, x = _rand_lp((M, N), g, dt), _rand_lp((M, K), g, dt)
+    dw, db = ops.gemm_wgrad(dy, x)
+    ref = dy.double().t() @ x.double()
+    scale = math.sqrt(M)
+    torch.testing.assert_close(dw.double() / scale, ref / scale, rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(db.double() / scale, dy.double().sum(0) / scale, rtol=1e-4, atol=1e-4)
+    # gathered X rows
+    rows = torch.randint(-1, M, (M,), generator=g).int().to(DEV)
+    dw2, _ = ops.gemm_wgrad(dy, x, x_rows=rows, want_bias=False)
+    xz = torch.cat([x.double(), torch.zeros(1, K, device=DEV, dtype=torch.double)])
+    torch.testing.assert_close(dw2.double() / scale, (dy.double().t() @ xz[rows.long()]) / scale, rtol=1e-4, atol=1e-4)
+
+
+def test_gemm_wgrad_asymmetric():
+    M, N, K = 64, 16, 16
+    dy = torch.zeros(M, N, device=DEV, dtype=torch.bfloat16)
+    x = torch.zeros(M, K, device=DEV, dtype=torch.bfloat16)
+    dy[5, 3] = 1.0
+    x[5, 9] = 2.0
+    dw, _ = ops.gemm_wgrad(dy, x)
+    want = torch.zeros(N, K, device=DEV)
+    want[3, 9] = 2.0
+    assert torch.equal(dw, want)
+
+
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dt", [0, 1])
+@pytest.mark.parametrize("channels_last", [False, True])
+def test_patchify(dt, channels_last):
+    BA, T, C, S, p = 3, 3, 13, 32, 8
+    g = torch.Generator().manual_seed(1)
+    img1 = (torch.rand(BA, C, S, S, generator=g) < 0.3).float().to(DEV)
+    nxt = (torch.rand(BA, T - 1, C, S, S, generator=g) < 0.3).float().to(DEV)
+    frames = torch.cat([img1.unsqueeze(1), nxt], 1).reshape(BA * T, C, S, S)
+    gh = S // p
+    pat = frames.reshape(BA * T, C, gh, p, gh, p)
+    if channels_last:
+        img1 = img1.permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)
+        nxt = nxt.permute(0, 1, 3, 4, 2).contiguous().permute(0, 1, 4, 2, 3)
+        want = pat.permute(0, 2, 4, 3, 5, 1)      # (py, px, c)
+    else:
+        want = pat.permute(0, 2, 4, 1, 3, 5)      # (c, py, px)
+    out = ops.patchify(img1, nxt, T, p, dt, channels_last_order=channels_last)
+    assert torch.equal(out.float(), want.reshape(BA * T * gh * gh, -1))
+
+
+@pytest.mark.parametrize("dt", [0, 1])
+def test_ce_argmax(dt):
+    BA, C, S, p = 3, 13, 32, 8
+    g = torch.Generator().manual_seed(2)
+    pred = (torch.randn(BA, 2, C, S, S, generator=g) * 2).to(DEV)
+    pred[0, 1, 0, 0, :8] = pred[0, 0, 0, 0, :8]          # exact ties -> class 0
+    target = (torch.rand(BA, C, S, S, generator=g) < 0.3).float().to(DEV)
+    target_cl = target.permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)
+    # patch layout: column = cls*V + (c*p + py)*p + px
+    gh = S // p
+    logits = pred.reshape(BA, 2, C, gh, p, gh, p).permute(0, 3, 5, 1, 2, 4, 6).reshape(BA * gh * gh, -1).contiguous()
+    r = ops.ce_argmax(logits, target_cl, p, dt, want_pred=True)
+    pd = pred.double().requires_grad_(True)
+    loss = torch.nn.functional.cross_entropy(pd, target.long())
+    loss.backward()
+    assert abs(r["loss"].item() - loss.item()) < 1e-5
+    want_ind = torch.argmax(torch.softmax(pred, 1), 1)
+    assert torch.equal(r["ind64"], want_ind) and torch.equal(r["ind8"].long(), want_ind)
+    assert torch.equal(r["pred"], pred)
+    dref = pd.grad.reshape(BA, 2, C, gh, p, gh, p).permute(0, 3, 5, 1, 2, 4, 6).reshape(BA * gh * gh, -1)
+    n = BA * C * S * S
+    torch.testing.assert_close(r["dlogits"].double() * n, dref * n, rtol=1e-2 if dt == 0 else 1e-5, atol=4e-3 if dt == 0 else 1e-6)
+
+
+def test_transpose_and_fill_rows():
+    BA, L, D = 3, 16, 32
+    g = torch.Generator().manual_seed(4)
+    src = torch.randn(BA * L, D, generator=g).to(DEV)
+    pos = torch.randn(L, D, generator=g).to(DEV)
+    out = ops.transpose_rows(src, pos, BA, L, D)
+    want = src.reshape(BA, L, D).permute(0, 2, 1).reshape(BA, L, D) + pos
+    assert torch.equal(out.reshape(BA, L, D), want)
+    gd = torch.randn(BA * L, D, generator=g).to(DEV)
+    gs = ops.transpose_rows_bwd(gd, BA, L, D)
+    assert torch.equal(gs.reshape(BA, L, D), gd.reshape(BA, D, L).permute(0, 2, 1))
+    fill = (torch.rand(BA * L, generator=g) < 0.4).int().to(DEV)
+    tok, t0 = torch.randn(D, generator=g).to(DEV), torch.randn(D, generator=g).to(DEV)
+    x = src.clone()
+    ops.fill_rows(x, fill, tok, t0, pos, BA, L)
+    want = torch.where(fill.bool().unsqueeze(1), (tok + t0).unsqueeze(0) + pos.repeat(BA, 1), src)
+    assert torch.equal(x, want)
+
+
+def test_cast_adamw_sumsq():
+    g = torch.Generator().manual_seed(6)
+    n = 100003
+    x = torch.randn(n, generator=g).to(DEV)
+    assert torch.equal(ops.cast(x, 0), x.to(torch.bfloat16))
+    assert torch.equal(ops.cast_back(ops.cast(x, 0)), x.to(torch.bfloat16).float())
+    assert abs(ops.sumsq(x).item() / (x.double() ** 2).sum().item() - 1) < 1e-6
+    pr = torch.nn.Parameter(torch.randn(n, generator=g).to(DEV))
+    opt = torch.optim.AdamW([pr], lr=1e-3, betas=(0.9, 0.95), weight_decay=0.05)
+    p2 = pr.detach().clone()
+    m, v = torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+    for step in range(1, 4):
+        grad = torch.randn(n, generator=g).to(DEV)
+        pr.grad = grad.clone()
+        opt.step()
+        ops.adamw(p2, grad, m, v, None, 1e-3, 0.9, 0.95, 1e-8, 0.05, step)
+        torch.testing.assert_close(p2, pr.detach(), rtol=1e-5, atol=1e-6)
+
+
+def test_iou_confusion_vs_oracle():
+    z = np.load(GOLD + "/standalone.npz")
+    pred = unpack(z["iou_pred_bits"], z["iou_shape"])
+    tgt = unpack(z["iou_tgt_bits"], z["iou_shape"])
+    for b in range(pred.shape[0]):
+        conf = ops.iou_confusion(torch.from_numpy(pred[b]).to(DEV), torch.from_numpy(tgt[b]).to(DEV)).cpu().numpy()
+        want = O.occupancy_confusions(torch.from_numpy(pred[b]), torch.from_numpy(tgt[b]))
+        assert np.array_equal(conf, want)
+        assert np.array_equal(np.array([O.occupancy_iou(c) for c in conf]), z["iou_every_batch"][b])
