@@ -103,7 +103,10 @@ typedef struct StarGemm {
     float* out_f32;         /* optional float32 [M(dest), N] */
     int32_t M, N, K;
     int32_t dt;
+    int32_t flags;          /* STAR_GEMM_* */
 } StarGemm;
+#define STAR_GEMM_RES_BY_AROW 1 /* residual row = A row % res_mod, and rows with a_rows[m] < 0 are written as zeros
+                                   (encode_partial: the patch embedding of a zero-padded slot is a zero row) */
 #define STAR_ACT_NONE 0
 #define STAR_ACT_GELU 1   /* exact erf GELU (timm Mlp act_layer=nn.GELU) */
 #define STAR_ACT_RELU 2   /* compressor ReLU (mae_base.py:284-287) */
@@ -161,6 +164,20 @@ int star_fill_rows(float* x, const int32_t* fill, const float* mask_token, const
  * transposed to [BA, D, L] and re-read as [BA, L, D]; then + pos.  src/dst float32. */
 int star_transpose_rows(const float* src, float* dst, const float* pos, int BA, int L, int D, void* stream);
 int star_transpose_rows_bwd(const float* gdst, float* gsrc, int BA, int L, int D, void* stream);
+
+/* Row gather / scatter of float32 matrices (the residual stream and its gradient).
+ *   gather : dst[m, :] = rows[m] >= 0 ? src[rows[m], :] : 0, written as float32 and/or `dt`
+ *   scatter: dst[rows[m], :] = src[m, :] for rows[m] >= 0 (dst must be zeroed by the caller when the
+ *            map is not onto); both for the gather/cat/slice steps of multiagent_mae.py:816-867. */
+int star_gather_rows(const float* src, const int32_t* rows, float* dst_f32, void* dst_lp, int M, int D, int dt, void* stream);
+int star_scatter_rows(const void* src, int src_dt, const int32_t* rows, float* dst, int M, int D, void* stream);
+/* Grouped column sums: out[g, :] = sum over rows r with (r / div) % mod == g and (sel == NULL or
+ * sel[r] matches want) of src[r, :].  src in `dt` (STAR_F32 reads float32).  Used for the gradients of
+ * decoder_temp_embed, mask_token and the patch-embedding bias.  ws float32 [64 * mod * D]. */
+int star_colsum_groups(const void* src, int dt, const int32_t* sel, int sel_nonneg, int R, int D, int div, int mod, float* ws,
+                       float* out, void* stream);
+/* dst[c, r] = cast(src[r, c]): the transposed low-precision copy of a weight used by the dX GEMMs. */
+int star_cast_transpose(const float* src, void* dst, int R, int C, int dt, void* stream);
 
 /* ---- parameter plumbing -----------------------------------------------------------------------------------
  * cast float32 -> dt for many tensors in one launch is done by star_cast; star_colsum gives bias grads. */

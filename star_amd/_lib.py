@@ -14,6 +14,7 @@ LIB_PATH = os.path.join(_HERE, "libstar_hip.so")
 
 BF16, F32 = 0, 1
 ACT_NONE, ACT_GELU, ACT_RELU, ACT_DGELU, ACT_DRELU = 0, 1, 2, 3, 4
+GEMM_RES_BY_AROW = 1
 
 _lib = None
 
@@ -25,6 +26,7 @@ class StarGemm(C.Structure):
         ("res2", C.c_void_p), ("res2_div", C.c_int32), ("res2_mod", C.c_int32),
         ("aux", C.c_void_p), ("act", C.c_int32), ("pre", C.c_void_p), ("out_lp", C.c_void_p),
         ("out_f32", C.c_void_p), ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32), ("dt", C.c_int32),
+        ("flags", C.c_int32),
     ]
 
 
@@ -50,6 +52,10 @@ _SIGS = {
     "star_fill_rows": (C.c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "star_transpose_rows": (C.c_int, [_P, _P, _P, _I, _I, _I, _P]),
     "star_transpose_rows_bwd": (C.c_int, [_P, _P, _I, _I, _I, _P]),
+    "star_gather_rows": (C.c_int, [_P, _P, _P, _P, _I, _I, _I, _P]),
+    "star_scatter_rows": (C.c_int, [_P, _I, _P, _P, _I, _I, _P]),
+    "star_colsum_groups": (C.c_int, [_P, _I, _P, _I, _I, _I, _I, _I, _P, _P, _P]),
+    "star_cast_transpose": (C.c_int, [_P, _P, _I, _I, _I, _P]),
     "star_cast": (C.c_int, [_P, _P, _L, _I, _P]),
     "star_cast_back": (C.c_int, [_P, _P, _L, _I, _P]),
     "star_adamw": (C.c_int, [_P, _P, _P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _I, _P]),

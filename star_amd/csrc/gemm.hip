@@ -177,11 +177,19 @@ __global__ __launch_bounds__(GT) void gemm_nt_kernel(const StarGemm g) {
         if (m >= M) continue;
         const long long d = g.c_rows ? (long long)g.c_rows[m] : (long long)m;
         if (d < 0) continue;
+        const bool by_arow = (g.flags & STAR_GEMM_RES_BY_AROW) != 0;
+        const long long arow = (by_arow && g.a_rows) ? (long long)g.a_rows[m] : d;
 #pragma unroll
         for (int a = 0; a < TN; ++a) {
             const int n0 = n_blk + wn * TN * 16 + a * 16 + lg * 4;
             if (n0 >= N) continue;
             float v[4] = {acc[a][b][0], acc[a][b][1], acc[a][b][2], acc[a][b][3]};
+            if (by_arow && arow < 0) {  // zero-padded slot: stays a zero row
+                const float z[4] = {0.f, 0.f, 0.f, 0.f};
+                if (out_lp) st4(out_lp + (size_t)d * N + n0, z);
+                if (g.out_f32) st4(g.out_f32 + (size_t)d * N + n0, z);
+                continue;
+            }
             if (g.bias) {
                 float t[4];
                 ld4(g.bias + n0, t);
@@ -207,7 +215,8 @@ __global__ __launch_bounds__(GT) void gemm_nt_kernel(const StarGemm g) {
                 for (int e = 0; e < 4; ++e) v[e] = t[e] > 0.f ? v[e] : 0.f;
             }
             if (g.res) {
-                const long long rr = g.res_mod > 0 ? d % g.res_mod : d;
+                const long long rb = by_arow ? arow : d;
+                const long long rr = g.res_mod > 0 ? rb % g.res_mod : rb;
                 float t[4];
                 ld4(g.res + (size_t)rr * N + n0, t);
 #pragma unroll

@@ -1,0 +1,333 @@
+"""Forward / backward orchestration of the STAR amortized-individual model over libstar_hip.so.
+
+This is the host side of the hot path (reference: AmortizedIndivMMAEViT.forward / .inference,
+star/models/multiagent_mae.py:946-1125).  Every arithmetic step is one C-ABI call (star_amd.ops); PyTorch
+allocates buffers and keeps the autograd graph edge (one autograd.Function for the whole model), nothing else.
+
+Row conventions (all matrices are [rows, features], rows contiguous):
+  frame f = ba*T + t      (agent-scene ba, timestamp t)       -- multiagent_mae.py:960
+  token row = f*L + tok   encoder side,  ba*L + tok decoder side
+  compressed row r = f*keep + j
+"""
+import math
+
+import torch
+
+from . import ops
+from ._lib import ACT_DGELU, ACT_DRELU, ACT_GELU, ACT_NONE, ACT_RELU, BF16, F32, GEMM_RES_BY_AROW
+
+_LINEARS_BLOCK = ("attn.qkv", "attn.proj", "mlp.fc1", "mlp.fc2")
+
+
+class Config:
+    def __init__(self, model):
+        pe = model.patch_embed
+        self.img = pe.img_size[0]
+        self.patch = pe.patch_size[0]
+        self.chans = model.in_chans
+        self.dim = model.pos_embed.shape[-1]
+        self.depth = len(model.blocks)
+        self.heads = model.blocks[0].attn.num_heads
+        self.ddim = model.decoder_pos_embed.shape[-1]
+        self.ddepth = len(model.decoder_blocks)
+        self.dheads = model.decoder_blocks[0].attn.num_heads
+        self.T = model.time_stamp
+        self.mask = model.mask_method
+        self.encode_partial = model.encode_partial
+        self.no_temp_emb = model.no_temp_emb
+        self.decode_singletemp = model.decode_singletemp
+        self.eps = model.blocks[0].norm1.eps
+        self.inter = model.compressor[0].out_features
+        self.grid = self.img // self.patch
+        self.L = self.grid * self.grid
+        self.V = self.chans * self.patch * self.patch
+
+
+def head_permutation(cfg, device):
+    """Row order of the fused prediction-head weight.  Reference rows are (py, px, c) per class
+    (mae_base.py:392-406 un-patchify order); the kernels want class-major (c, py, px) so that the 8
+    voxels of a patch row are contiguous.  Returns idx with new_row[n] = old_row[idx[n]]."""
+    p, c = cfg.patch, cfg.chans
+    cc, py, px = torch.meshgrid(torch.arange(c), torch.arange(p), torch.arange(p), indexing="ij")
+    return ((py * p + px) * c + cc).reshape(-1).to(device)
+
+
+class Weights:
+    """Low-precision copies of the parameters in the layouts the kernels read, refreshed when a
+    parameter's version counter changes (every optimizer step in training, never in inference)."""
+
+    def __init__(self):
+        self.cache = {}
+
+    def get(self, key, versions, build):
+        hit = self.cache.get(key)
+        if hit is not None and hit[0] == versions:
+            return hit[1]
+        val = build()
+        self.cache[key] = (versions, val)
+        return val
+
+
+def _lin(P, W, name, dt, transposed=False):
+    w = P[name + ".weight"]
+    key = (name, dt, transposed)
+    if transposed:
+        return W.get(key, w._version, lambda: ops.cast_transpose(w.detach(), dt))
+    return W.get(key, w._version, lambda: ops.cast(w.detach(), dt))
+
+
+def _heads(P, W, cfg, dt, transposed=False):
+    wo, wf = P["decoder_pred_occ.weight"], P["decoder_pred_free.weight"]
+    key = ("heads", dt, transposed)
+
+    def build():
+        idx = head_permutation(cfg, wo.device)
+        fused = torch.cat([wf.detach().index_select(0, idx), wo.detach().index_select(0, idx)], 0).contiguous()
+        return ops.cast_transpose(fused, dt) if transposed else ops.cast(fused, dt)
+
+    return W.get(key, (wo._version, wf._version), build)
+
+
+def _heads_bias(P, W, cfg):
+    bo, bf = P["decoder_pred_occ.bias"], P["decoder_pred_free.bias"]
+
+    def build():
+        idx = head_permutation(cfg, bo.device)
+        return torch.cat([bf.detach().index_select(0, idx), bo.detach().index_select(0, idx)], 0).contiguous()
+
+    return W.get(("heads_bias",), (bo._version, bf._version), build)
+
+
+def _patch_weight(P, W, cfg, dt, channels_last):
+    w = P["patch_embed.proj.weight"]
+
+    def build():
+        w2 = w.detach()
+        w2 = w2.permute(0, 2, 3, 1) if channels_last else w2     # (py, px, c) order for NHWC memory
+        return ops.cast(w2.reshape(w.shape[0], -1).contiguous(), dt)
+
+    return W.get(("patch", dt, channels_last), w._version, build)
+
+
+# -------------------------------------------------------------------------------------------------------
+def _block_fwd(x, P, W, pre, heads, nb, l, dt, eps, save, train):
+    d = x.shape[1]
+    hd = d // heads
+    h1, mean1, rstd1 = ops.layernorm_fwd(x, P[pre + "norm1.weight"], P[pre + "norm1.bias"], eps, dt, want_stats=train)
+    qkv, _, _ = ops.gemm(h1, _lin(P, W, pre + "attn.qkv", dt), bias=P[pre + "attn.qkv.bias"])
+    a, lse = ops.attn_fwd(qkv, nb, l, heads, hd)
+    _, x_mid, _ = ops.gemm(a, _lin(P, W, pre + "attn.proj", dt), bias=P[pre + "attn.proj.bias"], res=x, want_lp=False,
+                           want_f32=True, out_f32=None if train else x)
+    h2, mean2, rstd2 = ops.layernorm_fwd(x_mid, P[pre + "norm2.weight"], P[pre + "norm2.bias"], eps, dt, want_stats=train)
+    v, _, u = ops.gemm(h2, _lin(P, W, pre + "mlp.fc1", dt), bias=P[pre + "mlp.fc1.bias"], act=ACT_GELU, want_pre=train)
+    _, x_out, _ = ops.gemm(v, _lin(P, W, pre + "mlp.fc2", dt), bias=P[pre + "mlp.fc2.bias"], res=x_mid, want_lp=False,
+                           want_f32=True, out_f32=None if train else x_mid)
+    if train:
+        save.append(dict(pre=pre, x=x, mean1=mean1, rstd1=rstd1, h1=h1, qkv=qkv, a=a, lse=lse, x_mid=x_mid, mean2=mean2,
+                         rstd2=rstd2, h2=h2, u=u, v=v, heads=heads, nb=nb, l=l))
+    return x_out
+
+
+def _wg(grads, G, name, dy, x, x_rows=None):
+    """weight + bias gradient of Linear `name`, written into the caller's gradient views when given."""
+    dw, db = ops.gemm_wgrad(dy, x, x_rows=x_rows, dw=None if G is None else G[name + ".weight"],
+                            db=None if G is None else G[name + ".bias"])
+    grads[name + ".weight"], grads[name + ".bias"] = dw, db
+
+
+def _ln_bwd(grads, G, name, dy, x, P, mean, rstd, g_in=None):
+    g, g_lp, dgam, dbet = ops.layernorm_bwd(dy, x, P[name + ".weight"], mean, rstd, g_in=g_in,
+                                            dgamma=None if G is None else G[name + ".weight"],
+                                            dbeta=None if G is None else G[name + ".bias"])
+    grads[name + ".weight"], grads[name + ".bias"] = dgam, dbet
+    return g, g_lp
+
+
+def _block_bwd(g, g_lp, s, P, W, dt, grads, G=None):
+    pre = s["pre"]
+    heads, nb, l = s["heads"], s["nb"], s["l"]
+    hd = s["x"].shape[1] // heads
+    _wg(grads, G, pre + "mlp.fc2", g_lp, s["v"])
+    du, _, _ = ops.gemm(g_lp, _lin(P, W, pre + "mlp.fc2", dt, True), act=ACT_DGELU, aux=s["u"])
+    _wg(grads, G, pre + "mlp.fc1", du, s["h2"])
+    dh2, _, _ = ops.gemm(du, _lin(P, W, pre + "mlp.fc1", dt, True))
+    g1, g1_lp = _ln_bwd(grads, G, pre + "norm2", dh2, s["x_mid"], P, s["mean2"], s["rstd2"], g_in=g)
+    _wg(grads, G, pre + "attn.proj", g1_lp, s["a"])
+    da, _, _ = ops.gemm(g1_lp, _lin(P, W, pre + "attn.proj", dt, True))
+    dqkv = ops.attn_bwd(s["qkv"], s["a"], da, s["lse"], nb, l, heads, hd)
+    _wg(grads, G, pre + "attn.qkv", dqkv, s["h1"])
+    dh1, _, _ = ops.gemm(dqkv, _lin(P, W, pre + "attn.qkv", dt, True))
+    g0, g0_lp = _ln_bwd(grads, G, pre + "norm1", dh1, s["x"], P, s["mean1"], s["rstd1"], g_in=g1)
+    return g0, g0_lp
+
+
+# -------------------------------------------------------------------------------------------------------
+def forward(cfg, P, W, dt, imgs1, imgs_next, trans_matrices, num_agent, batch, mask_ratio, infer, train, noise=None, taps=None):
+    """Runs the model.  Returns (out, ctx): out = dict(loss [1], result, latent, ind); ctx feeds backward()."""
+    dev = imgs1.device
+    ba, c, hh, ww = imgs1.shape
+    assert hh == ww == cfg.img and c == cfg.chans, (imgs1.shape, cfg.img, cfg.chans)
+    T, L, D, Dd, p = cfg.T, cfg.L, cfg.dim, cfg.ddim, cfg.patch
+    if T > 1:
+        assert imgs_next.dim() == 5 and imgs_next.shape[1] == T - 1, imgs_next.shape   # multiagent_mae.py:959
+    n_frames = ba * T
+    random_mode = cfg.mask == "random"
+    save = [] if train else None
+
+    # ---- mask index build (K5) --------------------------------------------------------------------------
+    if random_mode:
+        keep = int(L * (1 - mask_ratio))                                  # mae_base.py:415
+        nrows = n_frames
+    else:
+        keep = math.ceil(L * (1 - (1.0 - 1.0 / T)))                       # multiagent_mae.py:805-810 (Q1)
+        nrows = ba
+    if noise is None:
+        noise = torch.rand(nrows, L, device=dev)                          # Q3: always drawn
+    assert tuple(noise.shape) == (nrows, L)
+    ids_shuffle, ids_restore = ops.mask_sort(noise)
+    src_row, dst_row, mask, fill = ops.build_rowmaps(ids_shuffle, ids_restore, ba, T, L, keep, random_mode, cfg.decode_singletemp)
+
+    # ---- encoder (K1, K2, K3, K4) -------------------------------------------------------------------------
+    channels_last = imgs1.stride(1) == 1 and c > 1
+    a_pe = ops.patchify(imgs1, imgs_next if T > 1 else None, T, p, dt, channels_last_order=channels_last)
+    w_pe = _patch_weight(P, W, cfg, dt, channels_last)
+    pos = P["pos_embed"][0, 1:]
+    if cfg.encode_partial:
+        _, x, _ = ops.gemm(a_pe, w_pe, bias=P["patch_embed.proj.bias"], res=pos, res_mod=L, a_rows=src_row, want_lp=False,
+                           want_f32=True, flags=GEMM_RES_BY_AROW)
+        l_enc = keep
+    else:
+        _, x, _ = ops.gemm(a_pe, w_pe, bias=P["patch_embed.proj.bias"], res=pos, res_mod=L, want_lp=False, want_f32=True)
+        l_enc = L
+    if taps is not None:
+        taps["x0"] = x.clone()
+    for i in range(cfg.depth):
+        x = _block_fwd(x, P, W, "blocks.%d." % i, cfg.heads, n_frames, l_enc, dt, cfg.eps, save, train)
+        if taps is not None:
+            taps["enc_blk%d" % i] = x.clone()
+    y, mean_e, rstd_e = ops.layernorm_fwd(x, P["norm.weight"], P["norm.bias"], cfg.eps, dt, want_stats=train)
+    if taps is not None:
+        taps["enc_norm"] = y.clone()
+    comp_rows = None if cfg.encode_partial else src_row
+    latent_lp, latent, _ = ops.gemm(y, _lin(P, W, "compressor.0", dt), m=n_frames * keep, bias=P["compressor.0.bias"],
+                                    act=ACT_RELU, a_rows=comp_rows, want_f32=True)
+
+    # ---- decoder ----------------------------------------------------------------------------------------------
+    z, _, _ = ops.gemm(latent_lp, _lin(P, W, "decompressor", dt), bias=P["decompressor.bias"])
+    dpos = P["decoder_pos_embed"][0, 1:]
+    temp = None if cfg.no_temp_emb else P["decoder_temp_embed"].reshape(T, Dd)
+    tok = P["mask_token"].reshape(Dd)
+    w_de = _lin(P, W, "decoder_embed", dt)
+    if not random_mode:
+        xd = torch.empty(ba * L, Dd, dtype=torch.float32, device=dev)
+        ops.gemm(z, w_de, bias=P["decoder_embed.bias"], c_rows=dst_row, out_rows=ba * L, res=dpos, res_mod=L, res2=temp,
+                 res2_div=keep, res2_mod=T, want_lp=False, want_f32=True, out_f32=xd)
+        if cfg.decode_singletemp:      # rows no slice of timestamp 0 covers: mask token, no temporal embedding
+            ops.fill_rows(xd, fill, tok, None, dpos, ba, L)
+    else:
+        val = torch.empty(ba * L, Dd, dtype=torch.float32, device=dev)
+        ops.gemm(z, w_de, bias=P["decoder_embed.bias"], c_rows=dst_row, out_rows=ba * L, res2=temp, res2_div=keep, res2_mod=T,
+                 want_lp=False, want_f32=True, out_f32=val)
+        ops.fill_rows(val, fill, tok, None if temp is None else temp[0], None, ba, L)
+        xd = ops.transpose_rows(val, dpos, ba, L, Dd)                      # Q2
+        if taps is not None:
+            taps["dec_val"] = val.clone()
+    if taps is not None:
+        taps["dec_x0"] = xd.clone()
+    for i in range(cfg.ddepth):
+        xd = _block_fwd(xd, P, W, "decoder_blocks.%d." % i, cfg.dheads, ba, L, dt, cfg.eps, save, train)
+        if taps is not None:
+            taps["dec_blk%d" % i] = xd.clone()
+    yd, mean_d, rstd_d = ops.layernorm_fwd(xd, P["decoder_norm.weight"], P["decoder_norm.bias"], cfg.eps, dt, want_stats=train)
+    if taps is not None:
+        taps["dec_norm"] = yd.clone()
+    _, logits, _ = ops.gemm(yd, _heads(P, W, cfg, dt), bias=_heads_bias(P, W, cfg), want_lp=False, want_f32=True)
+
+    # ---- loss, decision, fusion (K9, K10) -----------------------------------------------------------------------
+    ce = ops.ce_argmax(logits, imgs1, p, dt, want_pred=taps is not None, want_dlogits=train)
+    if taps is not None:
+        taps["pred"], taps["mask"], taps["ids_restore"] = ce["pred"], mask, ids_restore
+    theta = ops.warp_thetas(trans_matrices).to(dev, non_blocking=True)
+    na = num_agent if num_agent.is_cuda else num_agent.to(dev)
+    if na.dtype not in (torch.int32, torch.int64):
+        na = na.long()
+    result = ops.warp_fuse(ce["ind8"], theta, na.contiguous(), batch, ego=imgs1 if infer else None)
+    out = dict(loss=ce["loss"], result=result, latent=latent.reshape(n_frames, keep, cfg.inter), ind=ce["ind64"])
+    ctx = None
+    if train:
+        ctx = dict(save=save, a_pe=a_pe, channels_last=channels_last, src_row=src_row, dst_row=dst_row, fill=fill, x_enc=x,
+                   mean_e=mean_e, rstd_e=rstd_e, y=y, latent_lp=latent_lp, z=z, xd=xd, mean_d=mean_d, rstd_d=rstd_d, yd=yd,
+                   dlogits=ce["dlogits"], keep=keep, ba=ba, l_enc=l_enc, random_mode=random_mode)
+    return out, ctx
+
+
+def backward(cfg, P, W, dt, ctx, G=None, on_ready=None):
+    """Gradients of the mean cross-entropy w.r.t. every trainable parameter, keyed by state-dict name.
+    Parameters the path never touches (cls_token, temp_embed; Q5) and the frozen tables are absent.
+    G: optional dict name -> float32 view to write each gradient into (a flat gradient buffer).
+    on_ready: optional callback(stage) fired after the decoder half ("decoder") and at the end ("encoder"),
+    so that a data-parallel wrapper can start reducing finished buckets while the rest still runs."""
+    T, L, D, Dd = cfg.T, cfg.L, cfg.dim, cfg.ddim
+    ba, keep = ctx["ba"], ctx["keep"]
+    n_frames = ba * T
+    grads = {}
+    save = ctx["save"]
+    dlog = ctx["dlogits"]
+    # prediction heads
+    dw, db = ops.gemm_wgrad(dlog, ctx["yd"])
+    idx = head_permutation(cfg, dw.device)
+    V = cfg.V
+    for name, lo in (("decoder_pred_free", 0), ("decoder_pred_occ", V)):
+        gw = torch.empty(V, Dd, dtype=torch.float32, device=dw.device)
+        gb = torch.empty(V, dtype=torch.float32, device=dw.device)
+        gw.index_copy_(0, idx, dw[lo:lo + V])
+        gb.index_copy_(0, idx, db[lo:lo + V])
+        grads[name + ".weight"], grads[name + ".bias"] = gw, gb
+    dyd, _, _ = ops.gemm(dlog, _heads(P, W, cfg, dt, True))
+    g, g_lp = _ln_bwd(grads, G, "decoder_norm", dyd, ctx["xd"], P, ctx["mean_d"], ctx["rstd_d"])
+    for s in reversed(save[cfg.depth:]):
+        g, g_lp = _block_bwd(g, g_lp, s, P, W, dt, grads, G)
+    # temporal un-mixing backward: g is d/d(decoder input rows)
+    if ctx["random_mode"]:
+        g = ops.transpose_rows_bwd(g, ba, L, Dd)                                    # Q2 backward
+    fill, dst_row = ctx["fill"], ctx["dst_row"]
+    if ctx["random_mode"] or cfg.decode_singletemp:
+        gtok = ops.colsum_groups(g, 1, 1, sel=fill)                                 # rows that took the mask token
+        grads["mask_token"] = gtok.reshape(1, 1, Dd)
+    _, dye = ops.gather_rows(g, dst_row, dt=dt, want_f32=False)                     # [n_frames*keep, Dd]
+    if not cfg.no_temp_emb:
+        gt = ops.colsum_groups(dye, keep, T)
+        if ctx["random_mode"]:
+            gt[0] += gtok[0]                                                        # mask tokens carry temp_embed[0]
+        grads["decoder_temp_embed"] = gt.reshape(1, T, 1, Dd)
+    _wg(grads, G, "decoder_embed", dye, ctx["z"])
+    dz, _, _ = ops.gemm(dye, _lin(P, W, "decoder_embed", dt, True))
+    _wg(grads, G, "decompressor", dz, ctx["latent_lp"])
+    dlat, _, _ = ops.gemm(dz, _lin(P, W, "decompressor", dt, True), act=ACT_DRELU, aux=ctx["latent_lp"])
+    comp_rows = None if cfg.encode_partial else ctx["src_row"]
+    _wg(grads, G, "compressor.0", dlat, ctx["y"], x_rows=comp_rows)
+    if on_ready is not None:
+        on_ready("decoder")
+    rows_enc = n_frames * ctx["l_enc"]
+    dy, _, _ = ops.gemm(dlat, _lin(P, W, "compressor.0", dt, True), c_rows=comp_rows, out_rows=rows_enc)
+    g, g_lp = _ln_bwd(grads, G, "norm", dy, ctx["x_enc"], P, ctx["mean_e"], ctx["rstd_e"])
+    for s in reversed(save[:cfg.depth]):
+        g, g_lp = _block_bwd(g, g_lp, s, P, W, dt, grads, G)
+    # patch embedding
+    wshape = P["patch_embed.proj.weight"].shape
+    if cfg.encode_partial:
+        dw, _ = ops.gemm_wgrad(g_lp, ctx["a_pe"], x_rows=ctx["src_row"], want_bias=False)
+        db = ops.colsum_groups(g_lp, 1, 1, sel=ctx["src_row"], sel_nonneg=True).reshape(-1)   # padded slots carry no bias
+    else:
+        dw, db = ops.gemm_wgrad(g_lp, ctx["a_pe"])
+    if ctx["channels_last"]:
+        dw = dw.reshape(wshape[0], wshape[2], wshape[3], wshape[1]).permute(0, 3, 1, 2).contiguous()
+    grads["patch_embed.proj.weight"], grads["patch_embed.proj.bias"] = dw.reshape(wshape), db
+    if G is not None:   # the few gradients that are not written in place by a kernel
+        for name, val in grads.items():
+            if val.data_ptr() != G[name].data_ptr():
+                G[name].copy_(val.reshape(G[name].shape))
+                grads[name] = G[name]
+    if on_ready is not None:
+        on_ready("encoder")
+    return grads

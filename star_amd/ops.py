@@ -88,7 +88,7 @@ def layernorm_fwd(x, gamma, beta, eps, dt, want_stats=True):
     return y, mean, rstd
 
 
-def layernorm_bwd(dy, x, gamma, mean, rstd, g_in=None, want_lp=True, g_out=None):
+def layernorm_bwd(dy, x, gamma, mean, rstd, g_in=None, want_lp=True, g_out=None, dgamma=None, dbeta=None):
     """-> (g_out float32 [M,D] = g_in + dx, g_lp copy in dy's dtype or None, dgamma, dbeta)."""
     m, d = x.shape
     dt = L.dt_of(dy)
@@ -96,8 +96,10 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, g_in=None, want_lp=True, g_out=None)
     if g_out is None:
         g_out = torch.empty(m, d, dtype=torch.float32, device=x.device)
     g_lp = torch.empty(m, d, dtype=dy.dtype, device=x.device) if want_lp else None
-    dgamma = torch.empty(d, dtype=torch.float32, device=x.device)
-    dbeta = torch.empty(d, dtype=torch.float32, device=x.device)
+    if dgamma is None:
+        dgamma = torch.empty(d, dtype=torch.float32, device=x.device)
+    if dbeta is None:
+        dbeta = torch.empty(d, dtype=torch.float32, device=x.device)
     ws = torch.empty(L.lib().star_layernorm_bwd_ws(d), dtype=torch.float32, device=x.device)
     L.check(L.lib().star_layernorm_bwd(p(dy), p(x), p(gamma), p(mean), p(rstd), p(g_in), p(g_out), p(g_lp), p(dgamma),
                                        p(dbeta), p(ws), m, d, dt, L.stream()))
@@ -106,7 +108,8 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, g_in=None, want_lp=True, g_out=None)
 
 # ---------------------------------------------------------------------------------------------------
 def gemm(a, w, m=None, bias=None, act=ACT_NONE, res=None, res_mod=0, res2=None, res2_div=0, res2_mod=0, aux=None,
-         a_rows=None, c_rows=None, out_rows=None, want_pre=False, want_lp=True, want_f32=False, out_f32=None, out_lp=None):
+         a_rows=None, c_rows=None, out_rows=None, want_pre=False, want_lp=True, want_f32=False, out_f32=None, out_lp=None,
+         flags=0):
     """C = epilogue(A[a_rows] @ W^T).  a [*, K], w [N, K] same dtype (bf16 or f32).
     Returns (out_lp, out_f32, pre) -- entries not requested are None."""
     _cuda(a, w)
@@ -125,12 +128,12 @@ def gemm(a, w, m=None, bias=None, act=ACT_NONE, res=None, res_mod=0, res2=None, 
         out_f32 = (torch.zeros if c_rows is not None else torch.empty)(rows_out, n, dtype=torch.float32, device=dev)
     pre = torch.empty(rows_out, n, dtype=a.dtype, device=dev) if want_pre else None
     g = L.StarGemm(p(a), p(w), p(a_rows), p(c_rows), p(bias), p(res), res_mod, p(res2), res2_div, res2_mod, p(aux), act,
-                   p(pre), p(out_lp), p(out_f32), m, n, k, dt)
+                   p(pre), p(out_lp), p(out_f32), m, n, k, dt, flags)
     L.check(L.lib().star_gemm(C.byref(g), L.stream()))
     return out_lp, out_f32, pre
 
 
-def gemm_wgrad(dy, x, x_rows=None, want_bias=True, want_weight=True):
+def gemm_wgrad(dy, x, x_rows=None, want_bias=True, want_weight=True, dw=None, db=None):
     """dW [N,K] = dY^T X[x_rows], db [N] = colsum(dY)."""
     _cuda(dy, x)
     dt = L.dt_of(dy)
@@ -138,8 +141,12 @@ def gemm_wgrad(dy, x, x_rows=None, want_bias=True, want_weight=True):
     m, n = dy.shape
     k = x.shape[1]
     dev = dy.device
-    dw = torch.empty(n, k, dtype=torch.float32, device=dev) if want_weight else None
-    db = torch.empty(n, dtype=torch.float32, device=dev) if want_bias else None
+    if dw is None and want_weight:
+        dw = torch.empty(n, k, dtype=torch.float32, device=dev)
+    if db is None and want_bias:
+        db = torch.empty(n, dtype=torch.float32, device=dev)
+    assert dw is None or (dw.is_contiguous() and dw.numel() == n * k)
+    assert db is None or (db.is_contiguous() and db.numel() == n)
     ws = torch.empty(L.lib().star_gemm_wgrad_ws(m, n, k), dtype=torch.float32, device=dev)
     L.check(L.lib().star_gemm_wgrad(p(dy), p(x), p(x_rows), p(dw), p(db), p(ws), m, n, k, dt, L.stream()))
     return dw, db
@@ -219,6 +226,42 @@ def transpose_rows_bwd(gdst, ba, l, d):
     gsrc = torch.empty_like(gdst)
     L.check(L.lib().star_transpose_rows_bwd(p(gdst), p(gsrc), ba, l, d, L.stream()))
     return gsrc
+
+
+def gather_rows(src, rows, dt=None, want_f32=True):
+    """dst[m] = src[rows[m]] (zero row for -1); float32 and/or low-precision copies."""
+    m, d = rows.numel(), src.shape[1]
+    f32 = torch.empty(m, d, dtype=torch.float32, device=src.device) if want_f32 else None
+    lp = torch.empty(m, d, dtype=L.torch_dtype(dt), device=src.device) if dt is not None else None
+    L.check(L.lib().star_gather_rows(p(src), p(rows), p(f32), p(lp), m, d, dt if dt is not None else F32, L.stream()))
+    return f32, lp
+
+
+def scatter_rows(src, rows, out_rows):
+    """dst[rows[m]] = src[m]; rows not hit stay zero.  src float32 or bf16 -> float32 [out_rows, D]."""
+    m, d = src.shape
+    dst = torch.zeros(out_rows, d, dtype=torch.float32, device=src.device)
+    L.check(L.lib().star_scatter_rows(p(src), L.dt_of(src), p(rows), p(dst), m, d, L.stream()))
+    return dst
+
+
+def colsum_groups(src, div=1, mod=1, sel=None, sel_nonneg=False):
+    """out[g] = sum of rows r of src with (r // div) % mod == g (and sel[r] selected) -> float32 [mod, D]."""
+    r, d = src.shape
+    assert src.is_contiguous()
+    ws = torch.empty(64 * mod * d, dtype=torch.float32, device=src.device)
+    out = torch.empty(mod, d, dtype=torch.float32, device=src.device)
+    L.check(L.lib().star_colsum_groups(p(src), L.dt_of(src), p(sel), int(sel_nonneg), r, d, div, mod, p(ws), p(out), L.stream()))
+    return out
+
+
+def cast_transpose(src, dt):
+    """float32 [R, C] -> dt [C, R]."""
+    assert src.dtype == torch.float32 and src.is_contiguous() and src.dim() == 2
+    r, c = src.shape
+    dst = torch.empty(c, r, dtype=L.torch_dtype(dt), device=src.device)
+    L.check(L.lib().star_cast_transpose(p(src), p(dst), r, c, dt, L.stream()))
+    return dst
 
 
 def cast(src, dt):

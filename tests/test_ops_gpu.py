@@ -331,3 +331,50 @@ def test_iou_confusion_vs_oracle():
         want = O.occupancy_confusions(torch.from_numpy(pred[b]), torch.from_numpy(tgt[b]))
         assert np.array_equal(conf, want)
         assert np.array_equal(np.array([O.occupancy_iou(c) for c in conf]), z["iou_every_batch"][b])
+
+
+# ------------------------------------------------------------------------------------------------
+def _attn_ref(qkv, NB, L, H, hd, dout=None):
+    x = qkv.double().reshape(NB, L, 3, H, hd).permute(2, 0, 3, 1, 4).detach().requires_grad_(True)
+    q, k, v = x[0], x[1], x[2]
+    att = ((q @ k.transpose(-2, -1)) * hd ** -0.5).softmax(-1)
+    out = (att @ v).transpose(1, 2).reshape(NB * L, H * hd)
+    if dout is None:
+        return out.detach(), None
+    out.backward(dout.double())
+    return out.detach(), x.grad.permute(1, 3, 0, 2, 4).reshape(NB * L, 3 * H * hd)
+
+
+@pytest.mark.parametrize("dt", [0, 1])
+@pytest.mark.parametrize("NB,L,H,hd", [(2, 16, 2, 16), (3, 64, 3, 32), (2, 342, 2, 16), (1, 342, 3, 32), (2, 1024, 2, 32),
+                                       (1, 1024, 4, 16), (2, 256, 2, 64), (1, 100, 1, 64), (1, 4096, 1, 32)])
+def test_attention_fwd_bwd(dt, NB, L, H, hd):
+    g = torch.Generator().manual_seed(NB + L + H + hd)
+    qkv = _rand_lp((NB * L, 3 * H * hd), g, dt, 1.5)
+    dout = _rand_lp((NB * L, H * hd), g, dt)
+    out, lse = ops.attn_fwd(qkv, NB, L, H, hd)
+    ref, dref = _attn_ref(qkv, NB, L, H, hd, dout)
+    tol = dict(rtol=2e-2, atol=1e-2) if dt == 0 else dict(rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(out.double(), ref, **tol)
+    # log2-domain LSE against the definition
+    x = qkv.double().reshape(NB, L, 3, H, hd)
+    s = torch.einsum("blhd,bmhd->bhlm", x[:, :, 0], x[:, :, 1]) * hd ** -0.5
+    torch.testing.assert_close(lse.double(), torch.logsumexp(s, -1) / math.log(2.0), rtol=1e-3 if dt == 0 else 1e-5, atol=1e-3 if dt == 0 else 1e-5)
+    dqkv = ops.attn_bwd(qkv, out, dout, lse, NB, L, H, hd)
+    tolb = dict(rtol=3e-2, atol=4e-2) if dt == 0 else dict(rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(dqkv.double(), dref, **tolb)
+
+
+def test_attention_one_hot_rows_catch_layout_errors():
+    """Integer data: V rows one-hot, q.k chosen so that every query attends (almost) only to one key."""
+    NB, L, H, hd = 1, 64, 1, 32
+    qkv = torch.zeros(NB * L, 3, H, hd, device=DEV)
+    tgt = (torch.arange(L, device=DEV) * 7 + 3) % L
+    code = lambda idx: torch.stack([((idx >> b) & 1).float() * 2 - 1 for b in range(6)], 1) * 16.0  # noqa: E731
+    qkv[:, 0, 0, :6] = code(tgt)
+    qkv[:, 1, 0, :6] = code(torch.arange(L, device=DEV))
+    qkv[:, 2, 0, :] = (torch.arange(L, device=DEV).unsqueeze(1) * 5 + torch.arange(hd, device=DEV).unsqueeze(0)) % 11
+    q16 = qkv.reshape(NB * L, -1).to(torch.bfloat16)
+    out, _ = ops.attn_fwd(q16, NB, L, H, hd)
+    want = qkv[tgt, 2, 0, :]
+    torch.testing.assert_close(out.float(), want, rtol=0, atol=1e-2)
