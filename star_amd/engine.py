@@ -54,12 +54,15 @@ def head_permutation(cfg, device):
 
 class Weights:
     """Low-precision copies of the parameters in the layouts the kernels read, refreshed when a
-    parameter's version counter changes (every optimizer step in training, never in inference)."""
+    parameter's version counter changes (every optimizer step in training, never in inference) or when
+    `epoch` is bumped (the fused optimizer updates the flat parameter buffer behind autograd's back)."""
 
     def __init__(self):
         self.cache = {}
+        self.epoch = 0
 
     def get(self, key, versions, build):
+        versions = (versions, self.epoch)
         hit = self.cache.get(key)
         if hit is not None and hit[0] == versions:
             return hit[1]
@@ -126,6 +129,37 @@ def _block_fwd(x, P, W, pre, heads, nb, l, dt, eps, save, train):
         save.append(dict(pre=pre, x=x, mean1=mean1, rstd1=rstd1, h1=h1, qkv=qkv, a=a, lse=lse, x_mid=x_mid, mean2=mean2,
                          rstd2=rstd2, h2=h2, u=u, v=v, heads=heads, nb=nb, l=l))
     return x_out
+
+
+def _put(grads, G, name, val):
+    """record a gradient that no kernel wrote in place (copied into the caller's view when given)."""
+    if G is not None:
+        G[name].copy_(val.reshape(G[name].shape))
+        val = G[name]
+    grads[name] = val
+
+
+def stages(cfg):
+    """Parameter names grouped in the order their gradients complete in backward(); only parameters the
+    configured path really uses (the others never receive a gradient, reference Q5)."""
+    blk = ["norm1.weight", "norm1.bias", "attn.qkv.weight", "attn.qkv.bias", "attn.proj.weight", "attn.proj.bias",
+           "norm2.weight", "norm2.bias", "mlp.fc1.weight", "mlp.fc1.bias", "mlp.fc2.weight", "mlp.fc2.bias"]
+    out = [["decoder_pred_occ.weight", "decoder_pred_occ.bias", "decoder_pred_free.weight", "decoder_pred_free.bias",
+            "decoder_norm.weight", "decoder_norm.bias"]]
+    for i in reversed(range(cfg.ddepth)):
+        out.append(["decoder_blocks.%d.%s" % (i, n) for n in blk])
+    mid = []
+    if cfg.mask == "random" or cfg.decode_singletemp:
+        mid.append("mask_token")
+    if not cfg.no_temp_emb:
+        mid.append("decoder_temp_embed")
+    mid += ["decoder_embed.weight", "decoder_embed.bias", "decompressor.weight", "decompressor.bias",
+            "compressor.0.weight", "compressor.0.bias", "norm.weight", "norm.bias"]
+    out.append(mid)
+    for i in reversed(range(cfg.depth)):
+        out.append(["blocks.%d.%s" % (i, n) for n in blk])
+    out.append(["patch_embed.proj.weight", "patch_embed.proj.bias"])
+    return out
 
 
 def _wg(grads, G, name, dy, x, x_rows=None):
@@ -265,8 +299,8 @@ def backward(cfg, P, W, dt, ctx, G=None, on_ready=None):
     """Gradients of the mean cross-entropy w.r.t. every trainable parameter, keyed by state-dict name.
     Parameters the path never touches (cls_token, temp_embed; Q5) and the frozen tables are absent.
     G: optional dict name -> float32 view to write each gradient into (a flat gradient buffer).
-    on_ready: optional callback(stage) fired after the decoder half ("decoder") and at the end ("encoder"),
-    so that a data-parallel wrapper can start reducing finished buckets while the rest still runs."""
+    on_ready: optional callback(k) fired when the gradients of stages(cfg)[k] are complete (in stream
+    order), so that a data-parallel wrapper can reduce finished buckets while the rest still runs."""
     T, L, D, Dd = cfg.T, cfg.L, cfg.dim, cfg.ddim
     ba, keep = ctx["ba"], ctx["keep"]
     n_frames = ba * T
@@ -282,37 +316,48 @@ def backward(cfg, P, W, dt, ctx, G=None, on_ready=None):
         gb = torch.empty(V, dtype=torch.float32, device=dw.device)
         gw.index_copy_(0, idx, dw[lo:lo + V])
         gb.index_copy_(0, idx, db[lo:lo + V])
-        grads[name + ".weight"], grads[name + ".bias"] = gw, gb
+        _put(grads, G, name + ".weight", gw)
+        _put(grads, G, name + ".bias", gb)
     dyd, _, _ = ops.gemm(dlog, _heads(P, W, cfg, dt, True))
     g, g_lp = _ln_bwd(grads, G, "decoder_norm", dyd, ctx["xd"], P, ctx["mean_d"], ctx["rstd_d"])
+    stage = 0
+    if on_ready is not None:
+        on_ready(stage)
     for s in reversed(save[cfg.depth:]):
         g, g_lp = _block_bwd(g, g_lp, s, P, W, dt, grads, G)
+        stage += 1
+        if on_ready is not None:
+            on_ready(stage)
     # temporal un-mixing backward: g is d/d(decoder input rows)
     if ctx["random_mode"]:
         g = ops.transpose_rows_bwd(g, ba, L, Dd)                                    # Q2 backward
     fill, dst_row = ctx["fill"], ctx["dst_row"]
     if ctx["random_mode"] or cfg.decode_singletemp:
         gtok = ops.colsum_groups(g, 1, 1, sel=fill)                                 # rows that took the mask token
-        grads["mask_token"] = gtok.reshape(1, 1, Dd)
+        _put(grads, G, "mask_token", gtok.reshape(1, 1, Dd))
     _, dye = ops.gather_rows(g, dst_row, dt=dt, want_f32=False)                     # [n_frames*keep, Dd]
     if not cfg.no_temp_emb:
         gt = ops.colsum_groups(dye, keep, T)
         if ctx["random_mode"]:
             gt[0] += gtok[0]                                                        # mask tokens carry temp_embed[0]
-        grads["decoder_temp_embed"] = gt.reshape(1, T, 1, Dd)
+        _put(grads, G, "decoder_temp_embed", gt.reshape(1, T, 1, Dd))
     _wg(grads, G, "decoder_embed", dye, ctx["z"])
     dz, _, _ = ops.gemm(dye, _lin(P, W, "decoder_embed", dt, True))
     _wg(grads, G, "decompressor", dz, ctx["latent_lp"])
     dlat, _, _ = ops.gemm(dz, _lin(P, W, "decompressor", dt, True), act=ACT_DRELU, aux=ctx["latent_lp"])
     comp_rows = None if cfg.encode_partial else ctx["src_row"]
     _wg(grads, G, "compressor.0", dlat, ctx["y"], x_rows=comp_rows)
-    if on_ready is not None:
-        on_ready("decoder")
     rows_enc = n_frames * ctx["l_enc"]
     dy, _, _ = ops.gemm(dlat, _lin(P, W, "compressor.0", dt, True), c_rows=comp_rows, out_rows=rows_enc)
     g, g_lp = _ln_bwd(grads, G, "norm", dy, ctx["x_enc"], P, ctx["mean_e"], ctx["rstd_e"])
+    stage += 1
+    if on_ready is not None:
+        on_ready(stage)
     for s in reversed(save[:cfg.depth]):
         g, g_lp = _block_bwd(g, g_lp, s, P, W, dt, grads, G)
+        stage += 1
+        if on_ready is not None:
+            on_ready(stage)
     # patch embedding
     wshape = P["patch_embed.proj.weight"].shape
     if cfg.encode_partial:
@@ -322,12 +367,8 @@ def backward(cfg, P, W, dt, ctx, G=None, on_ready=None):
         dw, db = ops.gemm_wgrad(g_lp, ctx["a_pe"])
     if ctx["channels_last"]:
         dw = dw.reshape(wshape[0], wshape[2], wshape[3], wshape[1]).permute(0, 3, 1, 2).contiguous()
-    grads["patch_embed.proj.weight"], grads["patch_embed.proj.bias"] = dw.reshape(wshape), db
-    if G is not None:   # the few gradients that are not written in place by a kernel
-        for name, val in grads.items():
-            if val.data_ptr() != G[name].data_ptr():
-                G[name].copy_(val.reshape(G[name].shape))
-                grads[name] = G[name]
+    _put(grads, G, "patch_embed.proj.weight", dw.reshape(wshape))
+    _put(grads, G, "patch_embed.proj.bias", db)
     if on_ready is not None:
-        on_ready("encoder")
+        on_ready(stage + 1)
     return grads

@@ -36,6 +36,11 @@ class _StarFunction(torch.autograd.Function):
         grads = engine.backward(model._cfg(), ctx.P, model._weights, model._dt(), ctx.saved, G=model._grad_views,
                                 on_ready=model._on_grads_ready)
         ctx.saved = None
+        if model._grad_views is not None:
+            # flat-gradient mode (star_amd.optim.FlatAdamW): gradients were written straight into the flat
+            # buffer that param.grad already views; the upstream scale is applied inside the optimizer kernel
+            model._grad_scale = gloss.detach().reshape(1).float()
+            return (None, None, None) + (None,) * len(ctx.names)
         outs = [grads.get(n) for n in ctx.names]
         live = [g for g in outs if g is not None]
         torch._foreach_mul_(live, gloss)          # upstream scale (loss scaler); exact for powers of two
@@ -65,7 +70,8 @@ class AmortizedIndivMMAEViT(MultiAgentMaskedAutoencoderViT):
         self._weights = engine.Weights()
         self._config = None
         self._compute_dtype = os.environ.get("STAR_AMD_DTYPE", "bf16")
-        self._grad_views = None          # name -> view into a flat gradient buffer (star_amd.parallel / optimizer)
+        self._grad_views = None          # name -> view into a flat gradient buffer (star_amd.optim.FlatAdamW)
+        self._grad_scale = None          # device scalar: upstream gradient of the loss in flat-gradient mode
         self._on_grads_ready = None      # callback(stage) from the backward chain (bucketed all-reduce)
         self._noise_override = None      # tests: feed the mask noise instead of drawing it
         self._taps = None                # tests: dict that receives intermediate tensors

@@ -10,6 +10,48 @@ from . import _lib as L
 from ._lib import ACT_DGELU, ACT_DRELU, ACT_GELU, ACT_NONE, ACT_RELU, BF16, F32, p  # noqa: F401
 
 
+class Profiler:
+    """Optional per-launch HIP-event timing of the C-ABI calls (bench.py's roofline leg).  Events are
+    recorded on torch's current stream, which is the stream every kernel here is launched on."""
+
+    def __init__(self, tags=None):
+        self.tags, self.records = tags, []
+
+    def want(self, tag):
+        return self.tags is None or tag in self.tags
+
+    def summary(self):
+        torch.cuda.synchronize()
+        out = {}
+        for tag, flops, nbytes, e0, e1 in self.records:
+            d = out.setdefault(tag, dict(launches=0, ms=0.0, flops=0.0, bytes=0.0))
+            d["launches"] += 1
+            d["ms"] += e0.elapsed_time(e1)
+            d["flops"] += flops
+            d["bytes"] += nbytes
+        return out
+
+
+PROFILER = None
+
+
+class _timed:
+    def __init__(self, tag, flops=0.0, nbytes=0.0):
+        self.on = PROFILER is not None and PROFILER.want(tag)
+        self.tag, self.flops, self.nbytes = tag, flops, nbytes
+
+    def __enter__(self):
+        if self.on:
+            self.e0 = torch.cuda.Event(enable_timing=True)
+            self.e1 = torch.cuda.Event(enable_timing=True)
+            self.e0.record()
+
+    def __exit__(self, *exc):
+        if self.on:
+            self.e1.record()
+            PROFILER.records.append((self.tag, self.flops, self.nbytes, self.e0, self.e1))
+
+
 def _cuda(*ts):
     for t in ts:
         if t is not None and not t.is_cuda:
@@ -47,8 +89,9 @@ def warp_fuse(pred_u8, theta, num_agent, batch, ego=None):
     if ego is not None:
         assert ego.dtype == torch.float32 and tuple(ego.shape) == (ab, c, h, w)
         es = ego.stride()
-    L.check(L.lib().star_warp_fuse(p(pred_u8), p(ego), es[0], es[1], es[2], es[3], p(theta), p(num_agent),
-                                   int(num_agent.dtype == torch.int64), p(out), batch, a, c, h, w, L.stream()))
+    with _timed("warp_fuse", 0.0, float(ab) * (a + 1) * c * h * w * 4):   # (A+1) x 3.41 MB per ego frame
+        L.check(L.lib().star_warp_fuse(p(pred_u8), p(ego), es[0], es[1], es[2], es[3], p(theta), p(num_agent),
+                                       int(num_agent.dtype == torch.int64), p(out), batch, a, c, h, w, L.stream()))
     return out
 
 
@@ -84,7 +127,8 @@ def layernorm_fwd(x, gamma, beta, eps, dt, want_stats=True):
     y = torch.empty(m, d, dtype=L.torch_dtype(dt), device=x.device)
     mean = torch.empty(m, dtype=torch.float32, device=x.device) if want_stats else None
     rstd = torch.empty(m, dtype=torch.float32, device=x.device) if want_stats else None
-    L.check(L.lib().star_layernorm_fwd(p(x), p(gamma), p(beta), p(y), p(mean), p(rstd), m, d, float(eps), dt, L.stream()))
+    with _timed("layernorm_fwd", 0.0, float(m) * d * (4 + (2 if dt == BF16 else 4))):
+        L.check(L.lib().star_layernorm_fwd(p(x), p(gamma), p(beta), p(y), p(mean), p(rstd), m, d, float(eps), dt, L.stream()))
     return y, mean, rstd
 
 
@@ -101,8 +145,9 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, g_in=None, want_lp=True, g_out=None,
     if dbeta is None:
         dbeta = torch.empty(d, dtype=torch.float32, device=x.device)
     ws = torch.empty(L.lib().star_layernorm_bwd_ws(d), dtype=torch.float32, device=x.device)
-    L.check(L.lib().star_layernorm_bwd(p(dy), p(x), p(gamma), p(mean), p(rstd), p(g_in), p(g_out), p(g_lp), p(dgamma),
-                                       p(dbeta), p(ws), m, d, dt, L.stream()))
+    with _timed("layernorm_bwd", 0.0, float(m) * d * (4 + 4 + 4 + 2 * (2 if dt == BF16 else 4))):
+        L.check(L.lib().star_layernorm_bwd(p(dy), p(x), p(gamma), p(mean), p(rstd), p(g_in), p(g_out), p(g_lp), p(dgamma),
+                                           p(dbeta), p(ws), m, d, dt, L.stream()))
     return g_out, g_lp, dgamma, dbeta
 
 
@@ -129,7 +174,8 @@ def gemm(a, w, m=None, bias=None, act=ACT_NONE, res=None, res_mod=0, res2=None, 
     pre = torch.empty(rows_out, n, dtype=a.dtype, device=dev) if want_pre else None
     g = L.StarGemm(p(a), p(w), p(a_rows), p(c_rows), p(bias), p(res), res_mod, p(res2), res2_div, res2_mod, p(aux), act,
                    p(pre), p(out_lp), p(out_f32), m, n, k, dt, flags)
-    L.check(L.lib().star_gemm(C.byref(g), L.stream()))
+    with _timed("gemm_nt", 2.0 * m * n * k):
+        L.check(L.lib().star_gemm(C.byref(g), L.stream()))
     return out_lp, out_f32, pre
 
 
@@ -148,7 +194,8 @@ def gemm_wgrad(dy, x, x_rows=None, want_bias=True, want_weight=True, dw=None, db
     assert dw is None or (dw.is_contiguous() and dw.numel() == n * k)
     assert db is None or (db.is_contiguous() and db.numel() == n)
     ws = torch.empty(L.lib().star_gemm_wgrad_ws(m, n, k), dtype=torch.float32, device=dev)
-    L.check(L.lib().star_gemm_wgrad(p(dy), p(x), p(x_rows), p(dw), p(db), p(ws), m, n, k, dt, L.stream()))
+    with _timed("gemm_wgrad", 2.0 * m * n * k):
+        L.check(L.lib().star_gemm_wgrad(p(dy), p(x), p(x_rows), p(dw), p(db), p(ws), m, n, k, dt, L.stream()))
     return dw, db
 
 
@@ -160,7 +207,8 @@ def attn_fwd(qkv, nb, l, h, hd):
     assert qkv.is_contiguous() and qkv.numel() == nb * l * 3 * h * hd
     out = torch.empty(nb * l, h * hd, dtype=qkv.dtype, device=qkv.device)
     lse = torch.empty(nb, h, l, dtype=torch.float32, device=qkv.device)
-    L.check(L.lib().star_attn_fwd(p(qkv), p(out), p(lse), nb, l, h, hd, dt, L.stream()))
+    with _timed("attn_fwd", 4.0 * nb * h * l * l * hd):
+        L.check(L.lib().star_attn_fwd(p(qkv), p(out), p(lse), nb, l, h, hd, dt, L.stream()))
     return out, lse
 
 
@@ -169,7 +217,8 @@ def attn_bwd(qkv, out, dout, lse, nb, l, h, hd):
     assert qkv.is_contiguous() and out.is_contiguous() and dout.is_contiguous() and dout.dtype == qkv.dtype
     dqkv = torch.empty_like(qkv)
     delta = torch.empty(nb, h, l, dtype=torch.float32, device=qkv.device)
-    L.check(L.lib().star_attn_bwd(p(qkv), p(out), p(dout), p(lse), p(delta), p(dqkv), nb, l, h, hd, dt, L.stream()))
+    with _timed("attn_bwd", 10.0 * nb * h * l * l * hd):
+        L.check(L.lib().star_attn_bwd(p(qkv), p(out), p(dout), p(lse), p(delta), p(dqkv), nb, l, h, hd, dt, L.stream()))
     return dqkv
 
 
@@ -204,8 +253,9 @@ def ce_argmax(logits, target, patch, dt, want_pred=False, want_dlogits=True, wan
     nb = L.lib().star_ce_nblocks(ba, c, h, w)
     part = torch.empty(nb, dtype=torch.float32, device=dev) if want_loss else None
     loss = torch.empty(1, dtype=torch.float32, device=dev) if want_loss else None
-    L.check(L.lib().star_ce_argmax(p(logits), p(target), L.strides(target), p(ind64), p(ind8), p(pred), p(dlog), p(part),
-                                   ba, c, h, w, patch, dt, L.stream()))
+    with _timed("ce_argmax", 0.0, float(ba) * c * h * w * 16):            # 13.6 MB per frame
+        L.check(L.lib().star_ce_argmax(p(logits), p(target), L.strides(target), p(ind64), p(ind8), p(pred), p(dlog), p(part),
+                                       ba, c, h, w, patch, dt, L.stream()))
     if want_loss:
         L.check(L.lib().star_ce_finish(p(part), nb, ba * c * h * w, p(loss), L.stream()))
     return dict(loss=loss, ind64=ind64, ind8=ind8, pred=pred, dlogits=dlog)

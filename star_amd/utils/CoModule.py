@@ -1,0 +1,73 @@
+"""Train / infer step wrapper for the STAR completion model -- the reference's `CoModule`
+(star/utils/CoModule.py:13-41,91-156) for the `ind_mae` path: same constructor, attributes
+(`model`, `optimizer`, `scheduler`, `mae_loss_scaler`) and method signatures / return tuples.
+The vae / vqstar / late methods of the reference belong to other models and are not part of this path."""
+import math
+import sys
+
+import torch
+
+from .misc import NativeScalerWithGradNormCount as NativeScaler
+from .move_optim import optimizer_to
+
+
+class CoModule(object):
+    def __init__(self, model, optimizer, com, parallel=None):
+        """`parallel`: optional star_amd.parallel.SceneParallel (multi-GPU gradient averaging)."""
+        self.mae_loss_scaler = NativeScaler()
+        self.model = model
+        self.optimizer = optimizer
+        self.parallel = parallel
+        self.scheduler = None            # only the 'late' / 'vqvae' baselines of the reference use one
+        if com not in ("ind_mae", "joint_mae"):
+            raise NotImplementedError("star_amd accelerates the 'ind_mae' completion path; com=%r is out of scope" % (com,))
+
+    def resume_from_cpu(self, checkpoint, device, trainable=True):
+        """Load a (reference-format) checkpoint that was read with map_location='cpu', then move to `device`."""
+        self.model = self.model.cpu()
+        self.model.load_state_dict(checkpoint["model_state_dict"])
+        self.model = self.model.to(device)
+        if trainable:
+            self.optimizer.load_state_dict(checkpoint["optimizer_state_dict"])
+            optimizer_to(self.optimizer, device)
+            if checkpoint.get("mae_scaler_state_dict"):
+                self.mae_loss_scaler.load_state_dict(checkpoint["mae_scaler_state_dict"])
+
+    @staticmethod
+    def _unpack(data):
+        # NHWC -> NCHW as VIEWS (the kernels take strides): [A*B,1,H,W,C] -> [A*B,C,H,W]
+        bev_seq = data['bev_seq'].squeeze(1).permute(0, 3, 1, 2)
+        bev_seq_next = data['bev_seq_next']            # [A*B, T-1, H, W, C] or [A*B, 0]
+        if bev_seq_next.dim() > 2:
+            bev_seq_next = bev_seq_next.permute(0, 1, 4, 2, 3)
+        bev_teacher = data['bev_seq_teacher'].squeeze(1).permute(0, 3, 1, 2)
+        return bev_seq, bev_seq_next, bev_teacher, data['trans_matrices'], data['num_agent']
+
+    def step_mae_completion(self, data, batch_size, mask_ratio, loss_fn='mse', trainable=False):
+        bev_seq, bev_seq_next, bev_teacher, trans_matrices, num_agent_tensor = self._unpack(data)
+        loss, result, _, ind_pred = self.model(bev_seq, bev_seq_next, bev_teacher, trans_matrices, num_agent_tensor,
+                                               batch_size, mask_ratio=mask_ratio)
+        fused = trainable and getattr(self.optimizer, "is_star_flat", False)
+        if fused:
+            # enqueue the whole backward (and the bucketed gradient all-reduce) BEFORE the host reads the loss,
+            # so the GPU never idles on the .item() round trip; the finite check still precedes the update
+            loss.backward()
+        loss_value = loss.item()
+        if not math.isfinite(loss_value):
+            print("Loss is {}, stopping training".format(loss_value))
+            sys.exit(1)
+        if fused:
+            if self.parallel is not None:
+                self.parallel.finish()
+            self.optimizer.step()
+        elif trainable:
+            self.mae_loss_scaler(loss, self.optimizer, parameters=self.model.parameters(), update_grad=True)
+            self.optimizer.zero_grad()
+        return loss_value, result, ind_pred.detach()
+
+    def infer_mae_completion(self, data, batch_size, mask_ratio, loss_fn='mse'):
+        bev_seq, bev_seq_next, bev_teacher, trans_matrices, num_agent_tensor = self._unpack(data)
+        with torch.no_grad():
+            loss, result, latent, ind_pred = self.model.inference(bev_seq, bev_seq_next, bev_teacher, trans_matrices,
+                                                                  num_agent_tensor, batch_size, mask_ratio=mask_ratio)
+        return loss.item(), result, ind_pred.detach(), latent.detach()
