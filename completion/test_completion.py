@@ -1,0 +1,63 @@
+#!/usr/bin/env python3
+"""STAR scene-completion evaluation on MI355X -- the `ind_mae` path of the reference's
+completion/test_completion.py: load `checkpoint["model_state_dict"]`, run `infer_mae_completion` (ego slot = the
+agent's own input), accumulate the three-scale occupancy IoU per batch and print the average.
+Synthetic batches stand in for V2X-Sim (see train_completion.py)."""
+import argparse
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+from star.models import multiagent_mae  # noqa: E402
+from star.utils.CoModule import CoModule  # noqa: E402
+from star.utils.metrics import Metrics  # noqa: E402
+from star_amd.synthetic import make_batch  # noqa: E402
+
+
+def main(args):
+    device = torch.device("cuda")
+    num_agent = args.num_agent - 1 if args.no_cross_road else args.num_agent
+    model = multiagent_mae.__dict__[args.mae_model](norm_pix_loss=args.norm_pix_loss, time_stamp=args.time_stamp, mask_method=args.mask)
+    if args.resume:
+        checkpoint = torch.load(args.resume, map_location="cpu", weights_only=False)
+        model.load_state_dict(checkpoint["model_state_dict"])
+        print("Load model from {}, at epoch {}".format(args.resume, checkpoint["epoch"]))
+    model = model.to(device).set_compute_dtype(args.dtype)
+    model.eval()
+    optimizer = torch.optim.AdamW(model.parameters(), lr=args.lr)
+    co_module = CoModule(model, optimizer, args.com)
+    evaluator = Metrics(2, args.iters)
+    losses = 0.0
+    for it in range(args.iters):
+        data = make_batch(args.batch, num_agent, args.time_stamp, seed=10_000 + it, device=device)
+        loss, reconstruction, ind_pred, latent = co_module.infer_mae_completion(data, args.batch, args.mask_ratio)
+        teacher = data["bev_seq_teacher"].squeeze(1).permute(0, 3, 1, 2)
+        evaluator.add_batch(reconstruction, teacher.contiguous())
+        evaluator.update_IoU()
+        losses += loss
+    iou = evaluator.get_average_IoU()
+    print("Average loss {:.6f}".format(losses / args.iters))
+    print("Occupancy IoU  scale 1: {:.6f}  scale 1/2: {:.6f}  scale 1/4: {:.6f}".format(*iou))
+    return iou
+
+
+if __name__ == "__main__":
+    p = argparse.ArgumentParser()
+    p.add_argument("-d", "--data", default="synthetic", type=str)
+    p.add_argument("--batch", default=1, type=int)
+    p.add_argument("--lr", default=0.001, type=float)
+    p.add_argument("--resume", default="", type=str)
+    p.add_argument("--com", default="ind_mae", type=str)
+    p.add_argument("--no_cross_road", action="store_true")
+    p.add_argument("--num_agent", default=6, type=int)
+    p.add_argument("--mask_ratio", default=0.50, type=float)
+    p.add_argument("--mask", default="random", type=str, choices=["random", "complement"])
+    p.add_argument("--time_stamp", default=2, type=int)
+    p.add_argument("--mae_model", default="amortized_ind_patch8_light", type=str)
+    p.add_argument("--norm_pix_loss", default=False, type=bool)
+    p.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    p.add_argument("--iters", default=10, type=int, help="synthetic batches to evaluate")
+    main(p.parse_args())

@@ -1,0 +1,1 @@
+from star_amd.models import multiagent_mae  # noqa: F401

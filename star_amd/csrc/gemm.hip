@@ -282,7 +282,7 @@ __device__ __forceinline__ short4_t ds_read_tr16(const unsigned char* p) {
 
 __global__ __launch_bounds__(GT) void gemm_tn_bf16_kernel(const bf16_t* __restrict__ dY, const bf16_t* __restrict__ X,
                                                           const int32_t* __restrict__ x_rows, float* __restrict__ out,
-                                                          int M, int N, int K, int m_per_split) {
+                                                          float* __restrict__ bias_part, int M, int N, int K, int m_per_split) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int TILE_BYTES = WG_BKM * 256;
 
@@ -298,6 +298,9 @@ __global__ __launch_bounds__(GT) void gemm_tn_bf16_kernel(const bf16_t* __restri
     // staging: 64 rows x 16 chunks (16 B) per operand tile = 1024 chunks, 4 per thread
     const int ld_chunk = tid & 15, ld_row = tid >> 4;  // rows ld_row + 16*i
     uint4 ry[4], rx[4];
+    // bias gradient (column sums of dY) rides along in the k-tile-0 blocks: the dY chunks are in registers anyway
+    const bool do_bias = bias_part != nullptr && k_blk == 0;
+    float bsum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     const bool yin = n_blk + ld_chunk * 8 < N, xin = k_blk + ld_chunk * 8 < K;
     auto load_tile = [&](int m0) {
 #pragma unroll
@@ -315,6 +318,17 @@ __global__ __launch_bounds__(GT) void gemm_tn_bf16_kernel(const bf16_t* __restri
         }
     };
     auto store_tile = [&](int buf) {
+        if (do_bias) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const unsigned w[4] = {ry[i].x, ry[i].y, ry[i].z, ry[i].w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    bsum[2 * e] += __uint_as_float(w[e] << 16);
+                    bsum[2 * e + 1] += __uint_as_float(w[e] & 0xffff0000u);
+                }
+            }
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int row = ld_row + 16 * i;
@@ -372,6 +386,17 @@ __global__ __launch_bounds__(GT) void gemm_tn_bf16_kernel(const bf16_t* __restri
         }
         if (st + 1 < nsteps) store_tile(buf ^ 1);
         __syncthreads();
+    }
+    if (do_bias) {  // fold the 16 row lanes of every column chunk through LDS (all tiles are consumed by now)
+        float* sb = reinterpret_cast<float*>(smem);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) sb[(ld_row * 16 + ld_chunk) * 8 + e] = bsum[e];
+        __syncthreads();
+        if (tid < 128 && n_blk + tid < N) {
+            float a = 0.f;
+            for (int r = 0; r < 16; ++r) a += sb[(r * 16 + (tid >> 3)) * 8 + (tid & 7)];
+            bias_part[(size_t)split * N + n_blk + tid] = a;
+        }
     }
     // D[i = k][j = n]: lane holds n = .. + (lane & 15), k = .. + (lane >> 4) * 4 + e
     float* o = out + (size_t)split * N * K;
@@ -445,14 +470,27 @@ __global__ __launch_bounds__(GT) void gemm_tn_f32_kernel(const float* __restrict
     }
 }
 
-__global__ void slab_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ out, int64_t n4, int S) {
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
-        float4 a = reinterpret_cast<const float4*>(slabs)[i];
-        for (int s = 1; s < S; ++s) {
-            const float4 b = reinterpret_cast<const float4*>(slabs)[(int64_t)s * n4 + i];
-            a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+// one launch folds the split-M slabs into dW and the per-split bias partials into db, in a fixed order
+__global__ void wgrad_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ dW, int64_t n4, int S,
+                                    const float* __restrict__ bpart, float* __restrict__ db, int N, int SB) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const int64_t t0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (dW != nullptr && S > 1) {
+        for (int64_t i = t0; i < n4; i += stride) {
+            float4 a = reinterpret_cast<const float4*>(slabs)[i];
+            for (int s = 1; s < S; ++s) {
+                const float4 b = reinterpret_cast<const float4*>(slabs)[(int64_t)s * n4 + i];
+                a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+            }
+            reinterpret_cast<float4*>(dW)[i] = a;
         }
-        reinterpret_cast<float4*>(out)[i] = a;
+    }
+    if (db != nullptr) {
+        for (int64_t c = t0; c < N; c += stride) {
+            float a = 0.f;
+            for (int s = 0; s < SB; ++s) a += bpart[(int64_t)s * N + c];
+            db[c] = a;
+        }
     }
 }
 
@@ -469,20 +507,12 @@ __global__ __launch_bounds__(GT) void colsum_kernel(const T* __restrict__ dY, fl
     __syncthreads();
     if (rl == 0 && c < N) part[(size_t)blockIdx.y * N + c] = (s[0][threadIdx.x] + s[1][threadIdx.x]) + (s[2][threadIdx.x] + s[3][threadIdx.x]);
 }
-__global__ void colsum_reduce_kernel(const float* __restrict__ part, float* __restrict__ out, int N, int S) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= N) return;
-    float a = 0.f;
-    for (int s = 0; s < S; ++s) a += part[(size_t)s * N + c];
-    out[c] = a;
-}
-
 static void wgrad_plan(int M, int N, int K, int dt, int* S, int* m_per, int* SC, int* rows_per) {
     const int tile = dt == STAR_BF16 ? WG_TILE : 64;
     const int step = dt == STAR_BF16 ? WG_BKM : 16;
     const int tiles = cdiv(N, tile) * cdiv(K, tile);
-    int s = cdiv(1024, tiles);                 // aim for ~4 blocks per CU
-    const int max_s = cdiv(M, 4 * step);       // at least 4 reduction steps per split
+    int s = cdiv(512, tiles);                  // aim for ~2 blocks per CU: the slabs cost S x N x K x 8 bytes of traffic
+    const int max_s = cdiv(M, 8 * step);       // at least 8 reduction steps per split
     if (s > max_s) s = max_s;
     if (s < 1) s = 1;
     if (s > 64) s = 64;
@@ -500,7 +530,7 @@ extern "C" int64_t star_gemm_wgrad_ws(int M, int N, int K) {
     wgrad_plan(M, N, K, STAR_BF16, &S, &mp, &SC, &rp);
     wgrad_plan(M, N, K, STAR_F32, &S2, &mp2, &SC, &rp);
     if (S2 > S) S = S2;
-    return (int64_t)S * N * K + (int64_t)SC * N + 16;
+    return (int64_t)S * N * K + (int64_t)(SC > S ? SC : S) * N + 16;
 }
 
 extern "C" int star_gemm_wgrad(const void* dY, const void* X, const int32_t* x_rows, float* dW, float* db, float* ws,
@@ -513,33 +543,35 @@ extern "C" int star_gemm_wgrad(const void* dY, const void* X, const int32_t* x_r
     hipStream_t s = (hipStream_t)stream;
     int S, mp, SC, rp;
     wgrad_plan(M, N, K, dt, &S, &mp, &SC, &rp);
+    float* part = ws + (size_t)S * N * K;
+    int SB = 0;  // number of bias partial rows
     if (dW) {
         float* target = S == 1 ? dW : ws;
         if (dt == STAR_BF16) {
             dim3 grid(cdiv(N, WG_TILE) * cdiv(K, WG_TILE), S);
-            hipLaunchKernelGGL(gemm_tn_bf16_kernel, grid, dim3(GT), 4 * WG_BKM * 256, s, (const bf16_t*)dY, (const bf16_t*)X, x_rows, target, M, N, K, mp);
+            hipLaunchKernelGGL(gemm_tn_bf16_kernel, grid, dim3(GT), 4 * WG_BKM * 256, s, (const bf16_t*)dY, (const bf16_t*)X, x_rows, target,
+                               db ? part : (float*)nullptr, M, N, K, mp);
+            SB = db ? S : 0;
         } else {
             dim3 grid(cdiv(N, 64) * cdiv(K, 64), S);
             hipLaunchKernelGGL(gemm_tn_f32_kernel, grid, dim3(GT), 0, s, (const float*)dY, (const float*)X, x_rows, target, M, N, K, mp);
         }
         STAR_LAUNCH_CHECK("star_gemm_wgrad");
-        if (S > 1) {
-            const int64_t n4 = (int64_t)N * K / 4;
-            int gb = cdiv(n4, 256);
-            if (gb > 2048) gb = 2048;
-            hipLaunchKernelGGL(slab_reduce_kernel, dim3(gb), dim3(256), 0, s, ws, dW, n4, S);
-            STAR_LAUNCH_CHECK("star_gemm_wgrad(reduce)");
-        }
     }
-    if (db) {
-        float* part = ws + (size_t)S * N * K;
+    if (db && SB == 0) {  // fp32 path, or bias only: stand-alone column sums
         if (dt == STAR_BF16)
             hipLaunchKernelGGL(colsum_kernel<bf16_t>, dim3(cdiv(N, 64), SC), dim3(GT), 0, s, (const bf16_t*)dY, part, M, N, rp);
         else
             hipLaunchKernelGGL(colsum_kernel<float>, dim3(cdiv(N, 64), SC), dim3(GT), 0, s, (const float*)dY, part, M, N, rp);
         STAR_LAUNCH_CHECK("star_gemm_wgrad(colsum)");
-        hipLaunchKernelGGL(colsum_reduce_kernel, dim3(cdiv(N, 256)), dim3(256), 0, s, part, db, N, SC);
-        STAR_LAUNCH_CHECK("star_gemm_wgrad(colsum reduce)");
+        SB = SC;
+    }
+    if ((dW && S > 1) || db) {
+        const int64_t n4 = (int64_t)N * K / 4;
+        int gb = cdiv(dW && S > 1 ? n4 : N, 256);
+        if (gb > 2048) gb = 2048;
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(gb), dim3(256), 0, s, ws, (dW && S > 1) ? dW : (float*)nullptr, n4, S, part, db, N, SB);
+        STAR_LAUNCH_CHECK("star_gemm_wgrad(reduce)");
     }
     return 0;
 }

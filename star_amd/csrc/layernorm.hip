@@ -7,7 +7,7 @@
 
 #define LN_THREADS 256
 #define LN_MAXV 8          // float4 per lane: D <= 64*4*8 = 2048
-#define LN_BWD_BLOCKS 512  // partial dgamma/dbeta rows
+#define LN_BWD_BLOCKS 1024  // partial dgamma/dbeta rows
 
 template <typename T, int NV>
 __global__ __launch_bounds__(LN_THREADS) void ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
@@ -141,16 +141,23 @@ __global__ __launch_bounds__(LN_THREADS) void ln_bwd_kernel(const T* __restrict_
     }
 }
 
-__global__ void ln_bwd_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                     int nblocks, int D) {
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= 2 * D) return;
+// second stage: block = 64 columns x 4 row lanes over the partial rows, fixed order -> deterministic
+__global__ __launch_bounds__(256) void ln_bwd_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dgamma,
+                                                            float* __restrict__ dbeta, int nblocks, int D) {
+    __shared__ float s[4][64];
+    const int e = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
     float a = 0.f;
-    for (int b = 0; b < nblocks; ++b) a += ws[(size_t)b * 2 * D + e];
-    if (e < D) {
-        if (dgamma) dgamma[e] = a;
-    } else if (dbeta) {
-        dbeta[e - D] = a;
+    if (e < 2 * D)
+        for (int b = rl; b < nblocks; b += 4) a += ws[(size_t)b * 2 * D + e];
+    s[rl][threadIdx.x & 63] = a;
+    __syncthreads();
+    if (rl == 0 && e < 2 * D) {
+        a = (s[0][threadIdx.x] + s[1][threadIdx.x]) + (s[2][threadIdx.x] + s[3][threadIdx.x]);
+        if (e < D) {
+            if (dgamma) dgamma[e] = a;
+        } else if (dbeta) {
+            dbeta[e - D] = a;
+        }
     }
 }
 
@@ -197,7 +204,7 @@ extern "C" int star_layernorm_bwd(const void* dy, const float* x, const float* g
     const int nvec = (D / 4 + 63) / 64;
     if (nvec <= 1) LN_BWD(1); else if (nvec == 2) LN_BWD(2); else if (nvec == 3) LN_BWD(3); else if (nvec == 4) LN_BWD(4); else LN_BWD(LN_MAXV);
     STAR_LAUNCH_CHECK("star_layernorm_bwd");
-    hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3(cdiv(2 * D, 256)), dim3(256), 0, (hipStream_t)stream, ws, dgamma, dbeta, nb, D);
+    hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3(cdiv(2 * D, 64)), dim3(256), 0, (hipStream_t)stream, ws, dgamma, dbeta, nb, D);
     STAR_LAUNCH_CHECK("star_layernorm_bwd(reduce)");
     return 0;
 }
