@@ -362,7 +362,7 @@ def backward(cfg, P, W, dt, ctx, G=None, on_ready=None):
     wshape = P["patch_embed.proj.weight"].shape
     if cfg.encode_partial:
         dw, _ = ops.gemm_wgrad(g_lp, ctx["a_pe"], x_rows=ctx["src_row"], want_bias=False)
-        db = ops.colsum_groups(g_lp, 1, 1, sel=ctx["src_row"], sel_nonneg=True).reshape(-1)   # padded slots carry no bias
+        db = ops.colsum_groups(g, 1, 1, sel=ctx["src_row"], sel_nonneg=True).reshape(-1)   # padded slots carry no bias
     else:
         dw, db = ops.gemm_wgrad(g_lp, ctx["a_pe"])
     if ctx["channels_last"]:
