@@ -35,9 +35,23 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
     return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
 }
 
-__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+// erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7, i.e. float32 round-off level) on the v_rcp / v_exp units:
+// about a dozen VALU instructions instead of libm's ~50, which matters because the GELU epilogue of a
+// 128x128 tile with K = 384 would otherwise cost more cycles than the tile's MFMAs.
+__device__ __forceinline__ float erf_as(float x) {
+    const float ax = fabsf(x);
+    const float t = __builtin_amdgcn_rcpf(__builtin_fmaf(0.3275911f, ax, 1.0f));
+    float p = __builtin_fmaf(1.061405429f, t, -1.453152027f);
+    p = __builtin_fmaf(p, t, 1.421413741f);
+    p = __builtin_fmaf(p, t, -0.284496736f);
+    p = __builtin_fmaf(p, t, 0.254829592f);
+    const float e = __builtin_amdgcn_exp2f(-1.4426950408889634f * ax * ax);
+    const float r = 1.0f - p * t * e;
+    return copysignf(r, x);
+}
+__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erf_as(x * 0.70710678118654752f)); }
 __device__ __forceinline__ float dgelu_f(float x) {
-    return 0.5f * (1.0f + erff(x * 0.70710678118654752f)) + x * 0.3989422804014327f * expf(-0.5f * x * x);
+    return 0.5f * (1.0f + erf_as(x * 0.70710678118654752f)) + x * 0.3989422804014327f * __builtin_amdgcn_exp2f(-0.72134752044448170f * x * x);
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -235,6 +249,190 @@ __global__ __launch_bounds__(GT) void gemm_nt_kernel(const StarGemm g) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------------
+// bf16 fast path: the same 128x128 tile, but operands stream global -> LDS directly (buffer_load ... lds,
+// no staging registers) through an NST-deep ring with NST-1 stages in flight behind a COUNTED vmcnt, one
+// raw s_barrier per 32-deep k-step; out-of-range rows / gathered "-1" rows are zero-filled by the buffer
+// descriptor's range check.  With K = 256..1536 a tile has only 8..48 k-steps, so what matters is that
+// HBM/L2 latency is covered by loads issued three steps earlier (and by the second/third block resident on
+// the CU), not by one-step register prefetch.  LDS rows are 64 B; 16-byte chunk c of row r sits at
+// c ^ S[(r>>2)&3], S = {0,2,3,1}: conflict-free for the 16x16x32 fragment reads (ds_read_b128 lane groups).
+// The swizzle is applied on the SOURCE address (the LDS side of an LDS-DMA is lane-linear).
+// Epilogue: accumulators are staged through the (now idle) ring as fp32 [64][132] twice, so that bias /
+// activation / residual / row-scatter run on whole rows with 16-byte coalesced global accesses.
+#define NTF_BK 32
+__device__ __forceinline__ int ntf_swz(int row) { return (0x78 >> (((row >> 2) & 3) << 1)) & 3; }
+
+template <int NST>
+__global__ __launch_bounds__(GT) void gemm_nt_fast_kernel(const StarGemm g) {
+    constexpr int BM = 128, BN = 128, STAGE = (BM + BN) * 64, PF = NST - 1;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int M = g.M, N = g.N, K = g.K;
+    const int tiles_n = (N + BN - 1) / BN, tiles_m = (M + BM - 1) / BM;
+    const int tile = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+    const int m_blk = (tile / tiles_n) * BM, n_blk = (tile % tiles_n) * BN;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave & 1, wn = wave >> 1;
+    const int lr = lane & 15, lg = lane >> 4;
+
+    // ---- LDS-DMA addressing: a wave instruction fills 16 rows x 64 B = 1 KiB; this wave owns rows wave*32..+31
+    __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g.A), 0, 0x7fffffff, 0x00020000);
+    __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g.W), 0, 0x7fffffff, 0x00020000);
+    unsigned offA[2], offW[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int r = wave * 32 + j * 16 + (lane >> 2);
+        const int c = (lane & 3) ^ ntf_swz(r);
+        const int m = m_blk + r, n = n_blk + r;
+        long long src = -1;
+        if (m < M) src = g.a_rows ? (long long)g.a_rows[m] : (long long)m;
+        offA[j] = src >= 0 ? (unsigned)(src * K * 2 + c * 16) : 0x7fffffffu;
+        offW[j] = n < N ? (unsigned)((long long)n * K * 2 + c * 16) : 0x7fffffffu;
+    }
+    auto issue = [&](int kt) {
+        unsigned char* st = smem + (kt % NST) * STAGE;
+        const unsigned kb = kt * (NTF_BK * 2);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (__attribute__((address_space(3))) void*)(st + (wave * 32 + j * 16) * 64), 16,
+                                                     offA[j] + kb, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (__attribute__((address_space(3))) void*)(st + BM * 64 + (wave * 32 + j * 16) * 64), 16,
+                                                     offW[j] + kb, 0, 0, 0);
+        }
+    };
+
+    f32x4_t acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    // fragment addresses inside a stage (constant over k-steps)
+    int fw[4], fx[4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        const int rw_ = wn * 64 + a * 16 + lr, rx_ = wm * 64 + a * 16 + lr;
+        fw[a] = BM * 64 + rw_ * 64 + ((lg ^ ntf_swz(rw_)) << 4);
+        fx[a] = rx_ * 64 + ((lg ^ ntf_swz(rx_)) << 4);
+    }
+
+    const int nk = K / NTF_BK;
+    for (int s0 = 0; s0 < PF && s0 < nk; ++s0) issue(s0);
+    for (int kt = 0; kt < nk; ++kt) {
+        const int rem = min(nk - 1 - kt, PF - 1);   // stages allowed to stay in flight behind stage kt
+        if (rem >= 3) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+        else if (rem == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (rem == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (kt + PF < nk) issue(kt + PF);
+        const unsigned char* st = smem + (kt % NST) * STAGE;
+        short8_t w8[4], x8[4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) w8[a] = *reinterpret_cast<const short8_t*>(st + fw[a]);
+#pragma unroll
+        for (int b = 0; b < 4; ++b) x8[b] = *reinterpret_cast<const short8_t*>(st + fx[b]);
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+                acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, w8[a]), __builtin_bit_cast(bf16x8_t, x8[b]),
+                                                                    acc[a][b], 0, 0, 0);
+    }
+
+    // ---- epilogue through LDS: two halves of 64 rows, fp32 [64][132]
+    float* stg = reinterpret_cast<float*>(smem);
+    constexpr int LDP = 132;
+    bf16_t* out_lp = (bf16_t*)g.out_lp;
+    bf16_t* pre = (bf16_t*)g.pre;
+    const bf16_t* aux = (const bf16_t*)g.aux;
+    const bool by_arow = (g.flags & STAR_GEMM_RES_BY_AROW) != 0;
+    const int col4 = (tid & 31) << 2, rsub = tid >> 5;
+    const int n0 = n_blk + col4;
+    float bias4[4] = {0.f, 0.f, 0.f, 0.f};
+    if (g.bias && n0 < N) ld4(g.bias + n0, bias4);
+#pragma unroll 1
+    for (int half = 0; half < 2; ++half) {
+        __syncthreads();   // operand ring (or the previous half) fully consumed
+        if (wm == half) {
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+#pragma unroll
+                for (int a = 0; a < 4; ++a)
+                    *reinterpret_cast<f32x4_t*>(stg + (b * 16 + lr) * LDP + wn * 64 + a * 16 + lg * 4) = acc[a][b];
+        }
+        __syncthreads();
+#pragma unroll 2
+        for (int i = 0; i < 8; ++i) {
+            const int row = rsub + 8 * i;
+            const int m = m_blk + half * 64 + row;
+            if (m >= M || n0 >= N) continue;
+            const long long d = g.c_rows ? (long long)g.c_rows[m] : (long long)m;
+            if (d < 0) continue;
+            const long long arow = (by_arow && g.a_rows) ? (long long)g.a_rows[m] : d;
+            float v[4];
+            ld4(stg + row * LDP + col4, v);
+            if (by_arow && arow < 0) {
+                const float z[4] = {0.f, 0.f, 0.f, 0.f};
+                if (out_lp) st4(out_lp + (size_t)d * N + n0, z);
+                if (g.out_f32) st4(g.out_f32 + (size_t)d * N + n0, z);
+                continue;
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] += bias4[e];
+            if (pre) st4(pre + (size_t)d * N + n0, v);
+            if (g.act == STAR_ACT_GELU) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = gelu_f(v[e]);
+            } else if (g.act == STAR_ACT_RELU) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+            } else if (g.act == STAR_ACT_DGELU) {
+                float t[4];
+                ld4(aux + (size_t)m * N + n0, t);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] *= dgelu_f(t[e]);
+            } else if (g.act == STAR_ACT_DRELU) {
+                float t[4];
+                ld4(aux + (size_t)m * N + n0, t);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = t[e] > 0.f ? v[e] : 0.f;
+            }
+            if (g.res) {
+                const long long rb = by_arow ? arow : d;
+                const long long rr = g.res_mod > 0 ? rb % g.res_mod : rb;
+                float t[4];
+                ld4(g.res + (size_t)rr * N + n0, t);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] += t[e];
+            }
+            if (g.res2) {
+                const int rr = (m / g.res2_div) % g.res2_mod;
+                float t[4];
+                ld4(g.res2 + (size_t)rr * N + n0, t);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] += t[e];
+            }
+            if (out_lp) st4(out_lp + (size_t)d * N + n0, v);
+            if (g.out_f32) st4(g.out_f32 + (size_t)d * N + n0, v);
+        }
+    }
+}
+
+template <int NST>
+static int launch_nt_fast(const StarGemm* g, hipStream_t s) {
+    const int tiles = cdiv(g->M, 128) * cdiv(g->N, 128);
+    const size_t lds = (size_t)NST * 256 * 64;
+    static bool attr_done = false;
+    if (!attr_done && lds > 48 * 1024) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_fast_kernel<NST>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((gemm_nt_fast_kernel<NST>), dim3(tiles), dim3(GT), lds, s, *g);
+    return 0;
+}
+
 template <typename T, int TM, int TN>
 static int launch_nt(const StarGemm* g, hipStream_t s) {
     constexpr int BM = 32 * TM, BN = 32 * TN;
@@ -257,7 +455,11 @@ extern "C" int star_gemm(const StarGemm* g, void* stream) {
     if (g->M == 0) return 0;
     hipStream_t s = (hipStream_t)stream;
     const bool narrow = g->N <= 32;
-    if (g->dt == STAR_BF16) {
+    const bool fast_ok = g->dt == STAR_BF16 && !narrow && g->K % NTF_BK == 0 && (long long)g->N * g->K * 2 < 0x7fffffffLL &&
+                         ((reinterpret_cast<uintptr_t>(g->A) | reinterpret_cast<uintptr_t>(g->W)) & 15) == 0;
+    if (fast_ok) {
+        launch_nt_fast<3>(g, s);
+    } else if (g->dt == STAR_BF16) {
         if (narrow) launch_nt<bf16_t, 4, 1>(g, s); else launch_nt<bf16_t, 4, 4>(g, s);
     } else {
         if (narrow) launch_nt<float, 4, 1>(g, s); else launch_nt<float, 4, 4>(g, s);
@@ -413,6 +615,129 @@ __global__ __launch_bounds__(GT) void gemm_tn_bf16_kernel(const bf16_t* __restri
     }
 }
 
+// bf16 TN fast path: the same tile and fragment scheme, operands streamed by LDS-DMA through an NST-deep
+// ring (32 rows of m per stage) behind a counted vmcnt, exactly like gemm_nt_fast_kernel.  Rows past the end
+// of the matrices are zero-filled by the buffer range check (splits are multiples of 32 rows, so a stage
+// never straddles two splits).  The bias gradient costs no memory traffic at all: in the k-tile-0 blocks
+// one extra MFMA per n-tile multiplies the dY fragment with an all-ones A operand (row sums on the matrix core).
+template <int NST>
+__global__ __launch_bounds__(GT) void gemm_tn_fast_kernel(const bf16_t* __restrict__ dY, const bf16_t* __restrict__ X,
+                                                          float* __restrict__ out, float* __restrict__ bias_part, int M, int N, int K,
+                                                          int m_per_split) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int TB = 32 * 256, STAGE = 2 * TB, PF = NST - 1;
+    const int tiles_n = (N + WG_TILE - 1) / WG_TILE;
+    const int n_blk = (blockIdx.x % tiles_n) * WG_TILE, k_blk = (blockIdx.x / tiles_n) * WG_TILE;
+    const int split = blockIdx.y;
+    const int m_begin = split * m_per_split, m_end = min(M, m_begin + m_per_split);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wk = wave & 1, wn = wave >> 1;
+    const int lg = lane >> 4, lq = (lane & 15) >> 2, lp = lane & 3;
+
+    __amdgpu_buffer_rsrc_t rsY = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(dY), 0, (unsigned)((long long)M * N * 2), 0x00020000);
+    __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(X), 0, (unsigned)((long long)M * K * 2), 0x00020000);
+    unsigned offY[2], offX[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int r = wave * 8 + j * 4 + (lane >> 4);       // row inside the 32-row stage
+        const int pc = lane & 15;
+        const int col = (((pc >> 1) ^ tn_swz(r)) << 4) + ((pc & 1) << 3);
+        offY[j] = n_blk + col < N ? (unsigned)(((long long)(m_begin + r) * N + n_blk + col) * 2) : 0x80000000u;
+        offX[j] = k_blk + col < K ? (unsigned)(((long long)(m_begin + r) * K + k_blk + col) * 2) : 0x80000000u;
+    }
+    const unsigned stepY = 32u * N * 2, stepX = 32u * K * 2;
+    auto issue = [&](int st_) {
+        unsigned char* sb = smem + (st_ % NST) * STAGE;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsY, (__attribute__((address_space(3))) void*)(sb + (wave * 8 + j * 4) * 256), 16,
+                                                     offY[j] + st_ * stepY, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, (__attribute__((address_space(3))) void*)(sb + TB + (wave * 8 + j * 4) * 256), 16,
+                                                     offX[j] + st_ * stepX, 0, 0, 0);
+        }
+    };
+    f32x4_t acc[4][4], accb[4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        accb[a] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    }
+    const bool do_bias = bias_part != nullptr && k_blk == 0 && wk == 0;
+    const short one = (short)0x3F80;
+    const short8_t ones = (short8_t){one, one, one, one, one, one, one, one};
+    const int r0 = lg * 8 + lq;
+    int ax[4], ay[4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        ax[a] = TB + tn_off(r0, wk * 4 + a) + lp * 8;
+        ay[a] = tn_off(r0, wn * 4 + a) + lp * 8;
+    }
+    // rows r0 and r0+4 share the swizzle bits (row&3) only partly: recompute the +4 variants
+    int axh[4], ayh[4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        axh[a] = TB + tn_off(r0 + 4, wk * 4 + a) + lp * 8;
+        ayh[a] = tn_off(r0 + 4, wn * 4 + a) + lp * 8;
+    }
+    const int nsteps = (m_end - m_begin + 31) / 32;
+    for (int s0 = 0; s0 < PF && s0 < nsteps; ++s0) issue(s0);
+    for (int st = 0; st < nsteps; ++st) {
+        const int rem = min(nsteps - 1 - st, PF - 1);
+        if (rem >= 3) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+        else if (rem == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (rem == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (st + PF < nsteps) issue(st + PF);
+        const unsigned char* sb = smem + (st % NST) * STAGE;
+        short8_t fx[4], fy[4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            const short4_t lo = ds_read_tr16(sb + ax[a]), hi = ds_read_tr16(sb + axh[a]);
+            fx[a] = (short8_t){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        }
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const short4_t lo = ds_read_tr16(sb + ay[b]), hi = ds_read_tr16(sb + ayh[b]);
+            fy[b] = (short8_t){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        }
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+                acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, fx[a]), __builtin_bit_cast(bf16x8_t, fy[b]),
+                                                                    acc[a][b], 0, 0, 0);
+        if (do_bias) {
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+                accb[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, ones), __builtin_bit_cast(bf16x8_t, fy[b]),
+                                                                  accb[b], 0, 0, 0);
+        }
+    }
+    if (do_bias && lg == 0) {
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int n = n_blk + wn * 64 + b * 16 + (lane & 15);
+            if (n < N) bias_part[(size_t)split * N + n] = accb[b][0];
+        }
+    }
+    float* o = out + (size_t)split * N * K;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        const int n = n_blk + wn * 64 + b * 16 + (lane & 15);
+        if (n >= N) continue;
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            const int k0 = k_blk + wk * 64 + a * 16 + lg * 4;
+            if (k0 >= K) continue;
+            *reinterpret_cast<float4*>(o + (size_t)n * K + k0) = make_float4(acc[a][b][0], acc[a][b][1], acc[a][b][2], acc[a][b][3]);
+        }
+    }
+}
+
 // fp32 TN path: simple LDS-tiled kernel on v_mfma_f32_16x16x4_f32; one value per lane per operand.
 // Tile 64(k) x 64(n), 4 waves each 32x32, reduction step 16 rows.
 __global__ __launch_bounds__(GT) void gemm_tn_f32_kernel(const float* __restrict__ dY, const float* __restrict__ X,
@@ -511,7 +836,7 @@ static void wgrad_plan(int M, int N, int K, int dt, int* S, int* m_per, int* SC,
     const int tile = dt == STAR_BF16 ? WG_TILE : 64;
     const int step = dt == STAR_BF16 ? WG_BKM : 16;
     const int tiles = cdiv(N, tile) * cdiv(K, tile);
-    int s = cdiv(512, tiles);                  // aim for ~2 blocks per CU: the slabs cost S x N x K x 8 bytes of traffic
+    int s = cdiv(768, tiles);                  // aim for ~3 blocks per CU: the slabs cost S x N x K x 8 bytes of traffic
     const int max_s = cdiv(M, 8 * step);       // at least 8 reduction steps per split
     if (s > max_s) s = max_s;
     if (s < 1) s = 1;
@@ -549,8 +874,14 @@ extern "C" int star_gemm_wgrad(const void* dY, const void* X, const int32_t* x_r
         float* target = S == 1 ? dW : ws;
         if (dt == STAR_BF16) {
             dim3 grid(cdiv(N, WG_TILE) * cdiv(K, WG_TILE), S);
-            hipLaunchKernelGGL(gemm_tn_bf16_kernel, grid, dim3(GT), 4 * WG_BKM * 256, s, (const bf16_t*)dY, (const bf16_t*)X, x_rows, target,
-                               db ? part : (float*)nullptr, M, N, K, mp);
+            const bool fast = x_rows == nullptr && (long long)M * N * 2 < 0x7fffffffLL && (long long)M * K * 2 < 0x7fffffffLL &&
+                              ((reinterpret_cast<uintptr_t>(dY) | reinterpret_cast<uintptr_t>(X)) & 15) == 0;
+            if (fast)
+                hipLaunchKernelGGL(gemm_tn_fast_kernel<3>, grid, dim3(GT), 3 * 2 * 32 * 256, s, (const bf16_t*)dY, (const bf16_t*)X, target,
+                                   db ? part : (float*)nullptr, M, N, K, mp);
+            else
+                hipLaunchKernelGGL(gemm_tn_bf16_kernel, grid, dim3(GT), 4 * WG_BKM * 256, s, (const bf16_t*)dY, (const bf16_t*)X, x_rows, target,
+                                   db ? part : (float*)nullptr, M, N, K, mp);
             SB = db ? S : 0;
         } else {
             dim3 grid(cdiv(N, 64) * cdiv(K, 64), S);

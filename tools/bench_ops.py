@@ -1,0 +1,109 @@
+#!/usr/bin/env python3
+"""Micro-benchmarks of the kernel families at the shapes of the B=8 training step (GPU box only)."""
+import sys, os, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from star_amd import ops
+from star_amd._lib import ACT_GELU, ACT_DGELU, ACT_NONE
+
+dev = "cuda"
+M = int(os.environ.get("M", 40960))
+
+
+def timeit(fn, n=20):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n * 1e3  # us
+
+
+def gemm_cases():
+    g = torch.Generator().manual_seed(0)
+    rows = []
+    for name, N, K, kw in [
+        ("qkv      ", 1152, 384, dict(bias=True)),
+        ("proj+res ", 384, 384, dict(bias=True, res=True)),
+        ("fc1+gelu ", 1536, 384, dict(bias=True, act=ACT_GELU, pre=True)),
+        ("fc2+res  ", 384, 1536, dict(bias=True, res=True)),
+        ("dfc2 dgel", 1536, 384, dict(act=ACT_DGELU, aux=True)),
+        ("dfc1     ", 384, 1536, dict()),
+        ("dqkv     ", 384, 1152, dict()),
+        ("dec qkv  ", 768, 256, dict(bias=True)),
+        ("dec fc1  ", 1024, 256, dict(bias=True, act=ACT_GELU, pre=True)),
+        ("dec fc2  ", 256, 1024, dict(bias=True, res=True)),
+        ("heads    ", 1664, 256, dict(bias=True, f32=True)),
+    ]:
+        a = torch.randn(M, K, generator=g).to(dev).bfloat16()
+        w = (torch.randn(N, K, generator=g) * K ** -0.5).to(dev).bfloat16()
+        bias = torch.randn(N, generator=g).to(dev) if kw.get("bias") else None
+        res = torch.randn(M, N, generator=g).to(dev) if kw.get("res") else None
+        aux = torch.randn(M, N, generator=g).to(dev).bfloat16() if kw.get("aux") else None
+        f32 = bool(kw.get("res") or kw.get("f32"))
+        out32 = torch.empty(M, N, device=dev) if f32 else None
+        outlp = None if f32 else torch.empty(M, N, device=dev, dtype=torch.bfloat16)
+        fn = lambda: ops.gemm(a, w, bias=bias, act=kw.get("act", ACT_NONE), res=res, aux=aux, want_pre=bool(kw.get("pre")),
+                              want_lp=not f32, want_f32=f32, out_f32=out32, out_lp=outlp)
+        us = timeit(fn)
+        fl = 2.0 * M * N * K
+        byt = M * K * 2 + M * N * ((4 if f32 else 2) + (2 if kw.get("pre") else 0) + (4 if kw.get("res") else 0) + (2 if kw.get("aux") else 0))
+        rows.append((name, N, K, us, fl / us / 1e6, byt / us / 1e3))
+    return rows
+
+
+def wgrad_cases():
+    g = torch.Generator().manual_seed(0)
+    rows = []
+    for name, N, K in [("w qkv", 1152, 384), ("w proj", 384, 384), ("w fc1", 1536, 384), ("w fc2", 384, 1536), ("w dqkv", 768, 256),
+                       ("w dfc1", 1024, 256), ("w dfc2", 256, 1024), ("w heads", 1664, 256)]:
+        dy = torch.randn(M, N, generator=g).to(dev).bfloat16()
+        x = torch.randn(M, K, generator=g).to(dev).bfloat16()
+        dw = torch.empty(N, K, device=dev)
+        db = torch.empty(N, device=dev)
+        us = timeit(lambda: ops.gemm_wgrad(dy, x, dw=dw, db=db))
+        rows.append((name, N, K, us, 2.0 * M * N * K / us / 1e6, (M * (N + K) * 2) / us / 1e3))
+    return rows
+
+
+def attn_cases():
+    rows = []
+    g = torch.Generator().manual_seed(0)
+    for name, NB, L, H, hd in [("enc attn", M // 1024, 1024, 12, 32), ("dec attn", M // 1024, 1024, 16, 16)]:
+        qkv = torch.randn(NB * L, 3 * H * hd, generator=g).to(dev).bfloat16()
+        dout = torch.randn(NB * L, H * hd, generator=g).to(dev).bfloat16()
+        out, lse = ops.attn_fwd(qkv, NB, L, H, hd)
+        us = timeit(lambda: ops.attn_fwd(qkv, NB, L, H, hd))
+        rows.append((name + " fwd", H, hd, us, 4.0 * NB * H * L * L * hd / us / 1e6, NB * H * L * L / us / 1e3))
+        us = timeit(lambda: ops.attn_bwd(qkv, out, dout, lse, NB, L, H, hd))
+        rows.append((name + " bwd", H, hd, us, 10.0 * NB * H * L * L * hd / us / 1e6, 2 * NB * H * L * L / us / 1e3))
+    return rows
+
+
+def ln_cases():
+    rows = []
+    g = torch.Generator().manual_seed(0)
+    for D in (384, 256):
+        x = torch.randn(M, D, generator=g).to(dev)
+        gam, bet = torch.ones(D, device=dev), torch.zeros(D, device=dev)
+        y, mean, rstd = ops.layernorm_fwd(x, gam, bet, 1e-6, 0)
+        us = timeit(lambda: ops.layernorm_fwd(x, gam, bet, 1e-6, 0))
+        rows.append(("ln fwd", D, 0, us, 0.0, M * D * 6 / us / 1e3))
+        dy = torch.randn(M, D, generator=g).to(dev).bfloat16()
+        gin = torch.randn(M, D, generator=g).to(dev)
+        gout = torch.empty(M, D, device=dev)
+        us = timeit(lambda: ops.layernorm_bwd(dy, x, gam, mean, rstd, g_in=gin, g_out=gout))
+        rows.append(("ln bwd", D, 0, us, 0.0, M * D * 16 / us / 1e3))
+    return rows
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["gemm", "wgrad", "attn", "ln"]
+    for w in which:
+        rows = dict(gemm=gemm_cases, wgrad=wgrad_cases, attn=attn_cases, ln=ln_cases)[w]()
+        for name, a, b, us, tf, gbs in rows:
+            print("%-14s %5d %5d  %8.1f us  %7.1f TFLOP/s  %7.1f GB/s(or Gexp/s)" % (name, a, b, us, tf, gbs))
