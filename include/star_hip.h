@@ -126,7 +126,7 @@ int star_gemm_wgrad(const void* dY, const void* X, const int32_t* x_rows, float*
  * [NB, L, H*hd] in `dt`, lse float32 [NB, H, L] (log2-domain row log-sum-exp, kept for backward).
  * hd in {16, 32, 64}; any L >= 1. */
 int star_attn_fwd(const void* qkv, void* out, float* lse, int NB, int L, int H, int hd, int dt, void* stream);
-/* dqkv [NB, L, 3, H, hd] from dout [NB, L, H*hd]; delta float32 [NB, H, L] is workspace. */
+/* dqkv [NB, L, 3, H, hd] from dout [NB, L, H*hd]; delta float32 [2, NB, H, L] is workspace. */
 int star_attn_bwd(const void* qkv, const void* out, const void* dout, const float* lse, float* delta,
                   void* dqkv, int NB, int L, int H, int hd, int dt, void* stream);
 

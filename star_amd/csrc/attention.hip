@@ -37,14 +37,15 @@ template <int HD> struct ACfg {
     static constexpr int SH = CH == 2 ? 3 : (CH == 4 ? 2 : 1);
     static constexpr int TILE = 64 * RB;              // bytes of a 64-row tile
     static constexpr int NLD = (64 * CH + AT - 1) / AT;
+    static constexpr int RPP = 1024 / RB;             // rows per 1-KiB LDS-DMA piece
+    static constexpr int NP = 64 / RPP;               // pieces per 64-row image
 };
 
 template <int HD> __device__ __forceinline__ int row_off(int row, int chunk) {
     return row * ACfg<HD>::RB + ((chunk ^ ((row >> ACfg<HD>::SH) & (ACfg<HD>::CH - 1))) << 4);
 }
 template <int HD> __device__ __forceinline__ int tr_off(int row, int colbyte) {
-    if constexpr (HD == 64) return row * 128 + ((((colbyte >> 6) ^ ((row >> 1) & 1)) << 6) | (colbyte & 63));
-    return row * ACfg<HD>::RB + colbyte;
+    return row * ACfg<HD>::RB + ((((colbyte >> 4) ^ ((row >> ACfg<HD>::SH) & (ACfg<HD>::CH - 1))) << 4) | (colbyte & 15));
 }
 
 template <int HD> struct TileRegs { uint4 v[ACfg<HD>::NLD]; };
@@ -146,17 +147,91 @@ __device__ __forceinline__ void store_T(const f32x16_t (&acc)[ACfg<HD>::DB], flo
 }
 
 // ------------------------------------------------------------------------------------------------------
+// K/V (or Q/dO) tiles stream global -> LDS with buffer_load ... lds: no staging registers, and -- the point --
+// no compiler-placed vmcnt(0) in the loop.  One wave instruction fills 1 KiB = RPP rows of one 64-row image;
+// a lane's 16 bytes land lane-linearly, so the image's chunk swizzle is applied to the SOURCE address.  Rows
+// past the end of the sequence are zero-filled by the descriptor's range check.
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+__device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rs, unsigned char* lds, unsigned voff) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)lds, 16, voff, 0, 0, 0);
+}
+template <int HD> __device__ __forceinline__ unsigned dma_src(int piece, int lane, int64_t row_bytes) {
+    using C = ACfg<HD>;
+    const int row = piece * C::RPP + lane / C::CH, pc = lane % C::CH;
+    return (unsigned)(row * row_bytes + ((pc ^ ((row >> C::SH) & (C::CH - 1))) << 4));
+}
+template <int N> __device__ __forceinline__ void wait_vm() {
+    if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if constexpr (N == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+    else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    else if constexpr (N == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else if constexpr (N == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+    else static_assert(N <= 5, "wait_vm");
+}
+// a global load that must be complete before the DMA ring starts counting: consuming the registers here keeps the
+// compiler from re-inserting its own (conservative, full) vmcnt wait inside the loop
+__device__ __forceinline__ void pin(short8_t& v) {
+    typedef __attribute__((ext_vector_type(4))) int i4;
+    i4 t = __builtin_bit_cast(i4, v);
+    asm volatile("" : "+v"(t));
+    v = __builtin_bit_cast(short8_t, t);
+}
+// single-instruction 3-way maximum (the compiler's fmaxf puts a canonicalising v_max in front of every MFMA output)
+__device__ __forceinline__ float max3(float a, float b, float c) {
+    float d;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+__device__ __forceinline__ float xor32_max(float x) {
+    typedef __attribute__((ext_vector_type(2))) unsigned u2;
+    const unsigned u = __float_as_uint(x);
+    const u2 r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+
+// Transposed LDS reads as inline asm: the compiler treats the builtin as aliasing every LDS-DMA in flight and
+// puts a full vmcnt(0) in front of it, which would serialise the ring.  The asm form is invisible to its wait
+// insertion, so the matching lgkmcnt wait is explicit (tr_wait) and carries the registers as operands to pin
+// the order.
+__device__ __forceinline__ unsigned lds_u32(const unsigned char* p) {
+    return (unsigned)(uintptr_t)(__attribute__((address_space(3))) const unsigned char*)p;
+}
+template <int OFF> __device__ __forceinline__ short4_t tr16(unsigned addr) {
+    short4_t r;
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(OFF));
+    return r;
+}
+// the four 16-row k-slices of a 64-row image (rows +0, +16, +32, +48), low and high 8-row halves
+template <int RB> __device__ __forceinline__ void tr_issue(unsigned a_lo, unsigned a_hi, short4_t (&lo)[4], short4_t (&hi)[4]) {
+    lo[0] = tr16<0>(a_lo);        hi[0] = tr16<0>(a_hi);
+    lo[1] = tr16<16 * RB>(a_lo);  hi[1] = tr16<16 * RB>(a_hi);
+    lo[2] = tr16<32 * RB>(a_lo);  hi[2] = tr16<32 * RB>(a_hi);
+    lo[3] = tr16<48 * RB>(a_lo);  hi[3] = tr16<48 * RB>(a_hi);
+}
+__device__ __forceinline__ void tr_wait(short4_t (&lo)[4], short4_t (&hi)[4]) {
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(lo[0]), "+v"(lo[1]), "+v"(lo[2]), "+v"(lo[3]), "+v"(hi[0]), "+v"(hi[1]), "+v"(hi[2]), "+v"(hi[3]));
+}
+
+#define ONES8 ((short8_t){0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80})
+#define RESCALE_TH 8.0f   // log2 units: the running reference maximum is only raised when a row exceeds it by 2^8
+
+// Forward.  Stage (ring of 3) = K image | V image | [hd 16: 2 KiB of bf16 ones].  The softmax denominator comes
+// out of the matrix pipe: a ones row block appended to V^T (hd 16: the idle MFMA rows 16..31 read the ones area;
+// hd >= 32: one extra MFMA chain) -- the vector ALU, which bounds this kernel, only does max, fma, exp2, cvt.
 template <int HD>
 __global__ __launch_bounds__(AT) void attn_fwd_bf16_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
                                                            float* __restrict__ lse, int L, int H, float c) {
     using C = ACfg<HD>;
+    constexpr int NI = 2 * C::NP / 4;                           // DMA instructions per wave per tile
+    constexpr int STAGE = 2 * C::TILE + (HD == 16 ? 2048 : 0);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int h = blockIdx.y, nb = blockIdx.z;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h2 = lane >> 5;
+    const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h2 = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int64_t rs = (int64_t)3 * H * HD;
     const bf16_t* qb = qkv + (int64_t)nb * L * rs + h * HD;
-    const bf16_t* kb_ = qb + H * HD;
-    const bf16_t* vb_ = qb + 2 * H * HD;
     const int q0 = blockIdx.x * 128 + wave * 32;
     const int q = q0 + r;
 
@@ -166,36 +241,82 @@ __global__ __launch_bounds__(AT) void attn_fwd_bf16_kernel(const bf16_t* __restr
         qf[ks] = (short8_t){0, 0, 0, 0, 0, 0, 0, 0};
         if (q < L) qf[ks] = *reinterpret_cast<const short8_t*>(qb + (int64_t)q * rs + ks * 16 + 8 * h2);
     }
-    f32x16_t o[C::DB];
+    if constexpr (HD == 16) {
+        for (int i = tid; i < 3 * 128; i += AT) *reinterpret_cast<uint4*>(smem + (i >> 7) * STAGE + 2 * C::TILE + (i & 127) * 16) =
+            make_uint4(0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int ks = 0; ks < C::KS; ++ks) pin(qf[ks]);
+
+    __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(qb), 0, (unsigned)((L * rs - h * HD) * 2), 0x00020000);
+    unsigned src[NI];
+    int dst[NI];
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+        const int p = wave * NI + j, isv = p >= C::NP, pp = isv ? p - C::NP : p;
+        src[j] = dma_src<HD>(pp, lane, rs * 2) + (unsigned)((1 + isv) * H * HD * 2);
+        dst[j] = isv * C::TILE + pp * 1024;
+    }
+    const unsigned tile_step = (unsigned)(64 * rs * 2);
+    auto issue = [&](int t, int stage) {
+#pragma unroll
+        for (int j = 0; j < NI; ++j) dma16(rsrc, smem + stage * STAGE + dst[j], src[j] + (unsigned)t * tile_step);
+    };
+
+    f32x16_t o[C::DB], lacc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) lacc[e] = 0.f;
 #pragma unroll
     for (int db = 0; db < C::DB; ++db)
 #pragma unroll
         for (int e = 0; e < 16; ++e) o[db][e] = 0.f;
-    float m = -INFINITY, l = 0.f;
+    float m = -INFINITY;      // reference maximum the exponentials are taken against (raw score units)
 
-    const int nt = (L + 63) / 64;
-    TileRegs<HD> kr, vr;
-    load_tile<HD>(kr, kb_, rs, 0, L, tid);
-    load_tile<HD>(vr, vb_, rs, 0, L, tid);
-    store_row<HD>(smem, kr, tid);
-    store_tr<HD>(smem + C::TILE, vr, tid);
-    __syncthreads();
-    for (int it = 0; it < nt; ++it) {
-        const unsigned char* kl = smem + (it & 1) * 2 * C::TILE;
-        const unsigned char* vl = kl + C::TILE;
-        if (it + 1 < nt) {
-            load_tile<HD>(kr, kb_, rs, (it + 1) * 64, L, tid);
-            load_tile<HD>(vr, vb_, rs, (it + 1) * 64, L, tid);
+    // per-lane fragment offsets inside a stage
+    int koff[C::KS];
+#pragma unroll
+    for (int ks = 0; ks < C::KS; ++ks) koff[ks] = row_off<HD>(r, ks * 2 + h2);
+    const int g = lane >> 4, i16 = lane & 15;
+    const bool ones_lane = HD == 16 && (g & 1);
+    int voff[2][C::DB];       // [row | row+8][d block]
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int db = 0; db < C::DB; ++db) {
+            const int row = 4 * (g >> 1) + (i16 >> 2) + 8 * u;
+            const int colbyte = (db * 32 + (HD >= 32 ? (g & 1) : 0) * 16 + 4 * (i16 & 3)) * 2;
+            voff[u][db] = ones_lane ? 2 * C::TILE + (i16 & 3) * 8 + u * 32 : C::TILE + tr_off<HD>(row, colbyte);
         }
+
+    const unsigned lds_base = lds_u32(smem);
+    const int nt = (L + 63) / 64;
+    issue(0, 0);
+    if (nt > 1) issue(1, 1);
+    int stage = 0;
+    for (int it = 0; it < nt; ++it) {
+        if (it + 1 < nt) wait_vm<NI>(); else wait_vm<0>();
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (it + 2 < nt) issue(it + 2, stage >= 1 ? stage - 1 : 2);
+        const unsigned char* st = smem + stage * STAGE;
+        const unsigned sbase = lds_base + stage * STAGE;
+        stage = stage == 2 ? 0 : stage + 1;
+
         f32x16_t s[2];
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) s[kb][e] = 0.f;
 #pragma unroll
-            for (int ks = 0; ks < C::KS; ++ks) s[kb] = mfma32(row_frag<HD>(kl, kb * 32 + r, ks * 2 + h2), qf[ks], s[kb]);
+            for (int ks = 0; ks < C::KS; ++ks)
+                s[kb] = mfma32(*reinterpret_cast<const short8_t*>(st + koff[ks] + kb * 32 * C::RB), qf[ks], s[kb]);
         }
-        if ((it + 1) * 64 > L) {
+        // V^T fragments for the whole tile: issued now, waited on just before the PV products
+        short4_t vlo[C::DB][4], vhi[C::DB][4];
+#pragma unroll
+        for (int db = 0; db < C::DB; ++db) tr_issue<C::RB>(sbase + voff[0][db], sbase + voff[1][db], vlo[db], vhi[db]);
+        if ((it + 1) * 64 > L) {   // ragged last tile only (uniform branch)
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
@@ -204,54 +325,63 @@ __global__ __launch_bounds__(AT) void attn_fwd_bf16_kernel(const bf16_t* __restr
                     if (key >= L) s[kb][e] = -INFINITY;
                 }
         }
-        float mx = s[0][0];
+        float mx = max3(s[0][0], s[0][1], s[1][0]);
+        float mx2 = max3(s[1][1], s[0][2], s[0][3]);
+#pragma unroll
+        for (int e = 4; e < 16; e += 4) {
+            mx = max3(mx, s[0][e], s[0][e + 1]);
+            mx2 = max3(mx2, s[0][e + 2], s[0][e + 3]);
+        }
+#pragma unroll
+        for (int e = 2; e < 16; e += 4) {
+            mx = max3(mx, s[1][e], s[1][e + 1]);
+            if (e + 3 < 16) mx2 = max3(mx2, s[1][e + 2], s[1][e + 3]);
+        }
+        mx = xor32_max(max3(mx, mx2, s[1][15]));
+        if (__builtin_amdgcn_ballot_w64((mx - m) * c > RESCALE_TH) != 0) {   // rare after the first tiles (uniform branch)
+            const float mn = fmaxf(m, mx);
+            const float alpha = __builtin_amdgcn_exp2f((m - mn) * c);
+            m = mn;
+#pragma unroll
+            for (int db = 0; db < C::DB; ++db)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) o[db][e] *= alpha;
+            if constexpr (HD >= 32) lacc[0] *= alpha;
+        }
+        const float mc = m * c;
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) mx = fmaxf(mx, s[kb][e]);
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const float mn = fmaxf(m, mx);
-        const float alpha = __builtin_amdgcn_exp2f((m - mn) * c);
-        const float mc = mn * c;
-        m = mn;
-        l *= alpha;
-#pragma unroll
-        for (int db = 0; db < C::DB; ++db)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) o[db][e] *= alpha;
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kb][e], c, -mc));
-                s[kb][e] = pv;
-                l += pv;
-            }
+            for (int e = 0; e < 16; ++e) s[kb][e] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kb][e], c, -mc));
+        tr_wait(vlo[0], vhi[0]);
+        if constexpr (C::DB == 2) tr_wait(vlo[1], vhi[1]);
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
                 const bf16x8_t pf = cvt8(s[kb], s2);
 #pragma unroll
-                for (int db = 0; db < C::DB; ++db) o[db] = mfma32(tr_frag<HD>(vl, kb * 32, s2, db, lane), pf, o[db]);
+                for (int db = 0; db < C::DB; ++db) {
+                    const short4_t lo = vlo[db][kb * 2 + s2], hi = vhi[db][kb * 2 + s2];
+                    o[db] = mfma32((short8_t){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]}, pf, o[db]);
+                }
+                if constexpr (HD >= 32) lacc = mfma32(ONES8, pf, lacc);
             }
-        if (it + 1 < nt) {
-            unsigned char* nl = smem + ((it + 1) & 1) * 2 * C::TILE;
-            store_row<HD>(nl, kr, tid);
-            store_tr<HD>(nl + C::TILE, vr, tid);
-        }
-        __syncthreads();
     }
-    l += __shfl_xor(l, 32, 64);
+    const float l = HD == 16 ? o[0][8] : lacc[0];
     if (h2 == 0 && q < L) lse[((int64_t)nb * H + h) * L + q] = m * c + log2f(l);
+    __syncthreads();   // every wave is done with the ring before it becomes the store staging area
     store_T<HD>(o, 1.0f / l, smem + wave * 32 * C::RB, out + ((int64_t)nb * L + q0) * H * HD + h * HD, (int64_t)H * HD, L - q0, lane);
 }
 
-// delta[nb][h][l] = sum_d dO * O   (one thread per (row, head))
-template <typename T>
-__global__ void attn_delta_kernel(const T* __restrict__ out, const T* __restrict__ dout, float* __restrict__ delta, int NB, int L, int H, int hd) {
+// ws[0][nb][h][l] = sum_d dO * O (bf16 path: negated); bf16 path also ws[1][nb][h][l] = -lse / c, so that the
+// dK/dV kernel can start its S and dP accumulators from the row constants (one thread per (row, head))
+template <typename T, bool NEG>
+__global__ void attn_delta_kernel(const T* __restrict__ out, const T* __restrict__ dout, const float* __restrict__ lse,
+                                  float* __restrict__ ws, int NB, int L, int H, int hd, float inv_c) {
     const int64_t item = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (item >= (int64_t)NB * L * H) return;
+    const int64_t total = (int64_t)NB * L * H;
+    if (item >= total) return;
     const int h = (int)(item % H);
     const int64_t row = item / H;
     const T* a = out + row * H * hd + h * hd;
@@ -264,26 +394,36 @@ __global__ void attn_delta_kernel(const T* __restrict__ out, const T* __restrict
         s += x[0] * y[0] + x[1] * y[1] + x[2] * y[2] + x[3] * y[3];
     }
     const int nb = (int)(row / L), l = (int)(row % L);
-    delta[((int64_t)nb * H + h) * L + l] = s;
+    const int64_t o = ((int64_t)nb * H + h) * L + l;
+    if (NEG) {
+        ws[o] = -s;
+        ws[total + o] = -lse[o] * inv_c;
+    } else {
+        ws[o] = s;
+    }
 }
 
-// dQ: query on the lane (same skeleton as the forward)
+__device__ __forceinline__ short8_t join8(short4_t lo, short4_t hi) { return (short8_t){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]}; }
+
+// dQ: query on the lane (the forward's skeleton and ring).  Stage = K image | V image; K is read by rows for S
+// and transposed for dQ^T += K^T dS^T from the same image.  Keys past L need no mask: their K rows are zero.
 template <int HD>
 __global__ __launch_bounds__(AT) void attn_bwd_dq_bf16_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout,
-                                                              const float* __restrict__ lse, const float* __restrict__ delta,
+                                                              const float* __restrict__ lse, const float* __restrict__ ndelta,
                                                               bf16_t* __restrict__ dqkv, int L, int H, float c, float scale) {
     using C = ACfg<HD>;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // [2][K row | K tr | V row]
+    constexpr int NI = 2 * C::NP / 4;
+    constexpr int STAGE = 2 * C::TILE;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int h = blockIdx.y, nb = blockIdx.z;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h2 = lane >> 5;
+    const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h2 = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int64_t rs = (int64_t)3 * H * HD;
     const bf16_t* qb = qkv + (int64_t)nb * L * rs + h * HD;
-    const bf16_t* kb_ = qb + H * HD;
-    const bf16_t* vb_ = qb + 2 * H * HD;
     const int q0 = blockIdx.x * 128 + wave * 32;
     const int q = q0 + r;
     short8_t qf[C::KS], dof[C::KS];
-    float ls = INFINITY, dl = 0.f;
+    float ls = INFINITY, ndl = 0.f;
 #pragma unroll
     for (int ks = 0; ks < C::KS; ++ks) {
         qf[ks] = dof[ks] = (short8_t){0, 0, 0, 0, 0, 0, 0, 0};
@@ -294,31 +434,64 @@ __global__ __launch_bounds__(AT) void attn_bwd_dq_bf16_kernel(const bf16_t* __re
     }
     if (q < L) {
         ls = lse[((int64_t)nb * H + h) * L + q];
-        dl = delta[((int64_t)nb * H + h) * L + q];
+        ndl = ndelta[((int64_t)nb * H + h) * L + q];
     }
+#pragma unroll
+    for (int ks = 0; ks < C::KS; ++ks) {
+        pin(qf[ks]);
+        pin(dof[ks]);
+    }
+    asm volatile("" : "+v"(ls), "+v"(ndl));
+
+    __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(qb), 0, (unsigned)((L * rs - h * HD) * 2), 0x00020000);
+    unsigned src[NI];
+    int dst[NI];
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+        const int p = wave * NI + j, isv = p >= C::NP, pp = isv ? p - C::NP : p;
+        src[j] = dma_src<HD>(pp, lane, rs * 2) + (unsigned)((1 + isv) * H * HD * 2);
+        dst[j] = isv * C::TILE + pp * 1024;
+    }
+    const unsigned tile_step = (unsigned)(64 * rs * 2);
+    auto issue = [&](int t, int stage) {
+#pragma unroll
+        for (int j = 0; j < NI; ++j) dma16(rsrc, smem + stage * STAGE + dst[j], src[j] + (unsigned)t * tile_step);
+    };
+
     f32x16_t dq[C::DB];
 #pragma unroll
     for (int db = 0; db < C::DB; ++db)
 #pragma unroll
         for (int e = 0; e < 16; ++e) dq[db][e] = 0.f;
+    int koff[C::KS];
+#pragma unroll
+    for (int ks = 0; ks < C::KS; ++ks) koff[ks] = row_off<HD>(r, ks * 2 + h2);
+    const int g = lane >> 4, i16 = lane & 15;
+    int toff[2][C::DB];
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int db = 0; db < C::DB; ++db)
+            toff[u][db] = tr_off<HD>(4 * (g >> 1) + (i16 >> 2) + 8 * u, (db * 32 + (HD >= 32 ? (g & 1) : 0) * 16 + 4 * (i16 & 3)) * 2);
 
-    constexpr int STAGE = 3 * C::TILE;
+    const unsigned lds_base = lds_u32(smem);
     const int nt = (L + 63) / 64;
-    TileRegs<HD> kr, vr;
-    load_tile<HD>(kr, kb_, rs, 0, L, tid);
-    load_tile<HD>(vr, vb_, rs, 0, L, tid);
-    store_row<HD>(smem, kr, tid);
-    store_tr<HD>(smem + C::TILE, kr, tid);
-    store_row<HD>(smem + 2 * C::TILE, vr, tid);
-    __syncthreads();
+    issue(0, 0);
+    if (nt > 1) issue(1, 1);
+    int stage = 0;
     for (int it = 0; it < nt; ++it) {
-        const unsigned char* kl = smem + (it & 1) * STAGE;
-        const unsigned char* kt = kl + C::TILE;
-        const unsigned char* vl = kl + 2 * C::TILE;
-        if (it + 1 < nt) {
-            load_tile<HD>(kr, kb_, rs, (it + 1) * 64, L, tid);
-            load_tile<HD>(vr, vb_, rs, (it + 1) * 64, L, tid);
-        }
+        if (it + 1 < nt) wait_vm<NI>(); else wait_vm<0>();
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (it + 2 < nt) issue(it + 2, stage >= 1 ? stage - 1 : 2);
+        const unsigned char* kl = smem + stage * STAGE;
+        const unsigned char* vl = kl + C::TILE;
+        const unsigned sbase = lds_base + stage * STAGE;
+        stage = stage == 2 ? 0 : stage + 1;
+
+        short4_t klo[C::DB][4], khi[C::DB][4];
+#pragma unroll
+        for (int db = 0; db < C::DB; ++db) tr_issue<C::RB>(sbase + toff[0][db], sbase + toff[1][db], klo[db], khi[db]);
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
             f32x16_t s, dp;
@@ -326,50 +499,44 @@ __global__ __launch_bounds__(AT) void attn_bwd_dq_bf16_kernel(const bf16_t* __re
             for (int e = 0; e < 16; ++e) s[e] = dp[e] = 0.f;
 #pragma unroll
             for (int ks = 0; ks < C::KS; ++ks) {
-                s = mfma32(row_frag<HD>(kl, kb * 32 + r, ks * 2 + h2), qf[ks], s);
-                dp = mfma32(row_frag<HD>(vl, kb * 32 + r, ks * 2 + h2), dof[ks], dp);
+                s = mfma32(*reinterpret_cast<const short8_t*>(kl + koff[ks] + kb * 32 * C::RB), qf[ks], s);
+                dp = mfma32(*reinterpret_cast<const short8_t*>(vl + koff[ks] + kb * 32 * C::RB), dof[ks], dp);
             }
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int key = it * 64 + kb * 32 + (e & 3) + 8 * (e >> 2) + 4 * h2;
-                float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(s[e], c, -ls));
-                if (key >= L) pv = 0.f;
-                s[e] = pv * (dp[e] - dl);
+            for (int e = 0; e < 16; ++e) s[e] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[e], c, -ls)) * (dp[e] + ndl);
+            if (kb == 0) {
+                tr_wait(klo[0], khi[0]);
+                if constexpr (C::DB == 2) tr_wait(klo[1], khi[1]);
             }
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
                 const bf16x8_t dsf = cvt8(s, s2);
 #pragma unroll
-                for (int db = 0; db < C::DB; ++db) dq[db] = mfma32(tr_frag<HD>(kt, kb * 32, s2, db, lane), dsf, dq[db]);
+                for (int db = 0; db < C::DB; ++db) dq[db] = mfma32(join8(klo[db][kb * 2 + s2], khi[db][kb * 2 + s2]), dsf, dq[db]);
             }
         }
-        if (it + 1 < nt) {
-            unsigned char* nl = smem + ((it + 1) & 1) * STAGE;
-            store_row<HD>(nl, kr, tid);
-            store_tr<HD>(nl + C::TILE, kr, tid);
-            store_row<HD>(nl + 2 * C::TILE, vr, tid);
-        }
-        __syncthreads();
     }
+    __syncthreads();
     store_T<HD>(dq, scale, smem + wave * 32 * C::RB, dqkv + ((int64_t)nb * L + q0) * rs + h * HD, rs, L - q0, lane);
 }
 
-// dK, dV: key on the lane; sweeps the queries in tiles of 64
+// dK, dV: key on the lane; sweeps the queries in tiles of 64.  Stage = Q image | dO image | -lse/c [64] | -delta [64];
+// the S and dP accumulators START from the row constants, so p = exp2(c S') and dS = p dP' need no subtraction.
+// Query rows past L are zero (Q, dO and both constants): they add nothing to dK, dV.
 template <int HD>
 __global__ __launch_bounds__(AT) void attn_bwd_dkv_bf16_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout,
-                                                               const float* __restrict__ lse, const float* __restrict__ delta,
+                                                               const float* __restrict__ nlsc, const float* __restrict__ ndelta,
                                                                bf16_t* __restrict__ dqkv, int L, int H, float c, float scale) {
     using C = ACfg<HD>;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // [2][Q row | Q tr | dO row | dO tr | lse[64] | delta[64]]
+    constexpr int NI = 2 * C::NP / 4;
+    constexpr int STAGE = 2 * C::TILE + 512;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int h = blockIdx.y, nb = blockIdx.z;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h2 = lane >> 5;
+    const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h2 = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int64_t rs = (int64_t)3 * H * HD, ro = (int64_t)H * HD;
     const bf16_t* qb = qkv + (int64_t)nb * L * rs + h * HD;
-    const bf16_t* kb_ = qb + H * HD;
-    const bf16_t* vb_ = qb + 2 * H * HD;
     const bf16_t* dob = dout + (int64_t)nb * L * ro + h * HD;
-    const float* lsb = lse + ((int64_t)nb * H + h) * L;
-    const float* dlb = delta + ((int64_t)nb * H + h) * L;
     const int k0 = blockIdx.x * 128 + wave * 32;
     const int key = k0 + r;
     short8_t kf[C::KS], vf[C::KS];
@@ -377,72 +544,107 @@ __global__ __launch_bounds__(AT) void attn_bwd_dkv_bf16_kernel(const bf16_t* __r
     for (int ks = 0; ks < C::KS; ++ks) {
         kf[ks] = vf[ks] = (short8_t){0, 0, 0, 0, 0, 0, 0, 0};
         if (key < L) {
-            kf[ks] = *reinterpret_cast<const short8_t*>(kb_ + (int64_t)key * rs + ks * 16 + 8 * h2);
-            vf[ks] = *reinterpret_cast<const short8_t*>(vb_ + (int64_t)key * rs + ks * 16 + 8 * h2);
+            kf[ks] = *reinterpret_cast<const short8_t*>(qb + H * HD + (int64_t)key * rs + ks * 16 + 8 * h2);
+            vf[ks] = *reinterpret_cast<const short8_t*>(qb + 2 * H * HD + (int64_t)key * rs + ks * 16 + 8 * h2);
         }
     }
+#pragma unroll
+    for (int ks = 0; ks < C::KS; ++ks) {
+        pin(kf[ks]);
+        pin(vf[ks]);
+    }
+
+    __amdgpu_buffer_rsrc_t rsq = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(qb), 0, (unsigned)((L * rs - h * HD) * 2), 0x00020000);
+    __amdgpu_buffer_rsrc_t rsd = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(dob), 0, (unsigned)((L * ro - h * HD) * 2), 0x00020000);
+    const float* cst = ((wave & 1) ? ndelta : nlsc) + ((int64_t)nb * H + h) * L;
+    __amdgpu_buffer_rsrc_t rsc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(cst), 0, (unsigned)(L * 4), 0x00020000);
+    unsigned src[NI];
+    int dst[NI];
+    bool isd[NI];
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+        const int p = j * 4 + wave;   // hd >= 32: compile-time split between the two descriptors
+        isd[j] = p >= C::NP;
+        const int pp = isd[j] ? p - C::NP : p;
+        src[j] = dma_src<HD>(pp, lane, (isd[j] ? ro : rs) * 2);
+        dst[j] = isd[j] * C::TILE + pp * 1024;
+    }
+    const unsigned step_q = (unsigned)(64 * rs * 2), step_d = (unsigned)(64 * ro * 2);
+    const int cdst = 2 * C::TILE + (wave & 1) * 256;
+    auto issue = [&](int t, int stage) {
+        unsigned char* sb = smem + stage * STAGE;
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            if (isd[j]) dma16(rsd, sb + dst[j], src[j] + (unsigned)t * step_d);
+            else dma16(rsq, sb + dst[j], src[j] + (unsigned)t * step_q);
+        }
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsc, (lds_ptr_t)(sb + cdst), 4, (unsigned)((t * 64 + lane) * 4), 0, 0, 0);
+    };
+
     f32x16_t dk[C::DB], dv[C::DB];
 #pragma unroll
     for (int db = 0; db < C::DB; ++db)
 #pragma unroll
         for (int e = 0; e < 16; ++e) dk[db][e] = dv[db][e] = 0.f;
+    int koff[C::KS];
+#pragma unroll
+    for (int ks = 0; ks < C::KS; ++ks) koff[ks] = row_off<HD>(r, ks * 2 + h2);
+    const int g = lane >> 4, i16 = lane & 15;
+    int toff[2][C::DB];
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int db = 0; db < C::DB; ++db)
+            toff[u][db] = tr_off<HD>(4 * (g >> 1) + (i16 >> 2) + 8 * u, (db * 32 + (HD >= 32 ? (g & 1) : 0) * 16 + 4 * (i16 & 3)) * 2);
 
-    constexpr int STAGE = 4 * C::TILE + 512;
+    const unsigned lds_base = lds_u32(smem);
     const int nt = (L + 63) / 64;
-    TileRegs<HD> qr, dr;
-    float lsr = INFINITY, dlr = 0.f;
-    auto fetch = [&](int t0) {
-        load_tile<HD>(qr, qb, rs, t0, L, tid);
-        load_tile<HD>(dr, dob, ro, t0, L, tid);
-        lsr = INFINITY;
-        dlr = 0.f;
-        if (tid < 64 && t0 + tid < L) {
-            lsr = lsb[t0 + tid];
-            dlr = dlb[t0 + tid];
-        }
-    };
-    auto stash = [&](unsigned char* st) {
-        store_row<HD>(st, qr, tid);
-        store_tr<HD>(st + C::TILE, qr, tid);
-        store_row<HD>(st + 2 * C::TILE, dr, tid);
-        store_tr<HD>(st + 3 * C::TILE, dr, tid);
-        if (tid < 64) {
-            reinterpret_cast<float*>(st + 4 * C::TILE)[tid] = lsr;
-            reinterpret_cast<float*>(st + 4 * C::TILE + 256)[tid] = dlr;
-        }
-    };
-    fetch(0);
-    stash(smem);
-    __syncthreads();
+    issue(0, 0);
+    if (nt > 1) issue(1, 1);
+    int stage = 0;
     for (int it = 0; it < nt; ++it) {
-        const unsigned char* st = smem + (it & 1) * STAGE;
-        const unsigned char* ql = st;
-        const unsigned char* qt = st + C::TILE;
-        const unsigned char* dol = st + 2 * C::TILE;
-        const unsigned char* dot = st + 3 * C::TILE;
-        const float* lsl = reinterpret_cast<const float*>(st + 4 * C::TILE);
+        if (it + 1 < nt) wait_vm<NI + 1>(); else wait_vm<0>();
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (it + 2 < nt) issue(it + 2, stage >= 1 ? stage - 1 : 2);
+        const unsigned char* ql = smem + stage * STAGE;
+        const unsigned char* dol = ql + C::TILE;
+        const float* lsl = reinterpret_cast<const float*>(ql + 2 * C::TILE);
         const float* dll = lsl + 64;
-        if (it + 1 < nt) fetch((it + 1) * 64);
+        const unsigned sbase = lds_base + stage * STAGE;
+        stage = stage == 2 ? 0 : stage + 1;
+
+        short4_t qlo[C::DB][4], qhi[C::DB][4], dlo[C::DB][4], dhi[C::DB][4];
+#pragma unroll
+        for (int db = 0; db < C::DB; ++db) {
+            tr_issue<C::RB>(sbase + toff[0][db], sbase + toff[1][db], qlo[db], qhi[db]);
+            tr_issue<C::RB>(sbase + C::TILE + toff[0][db], sbase + C::TILE + toff[1][db], dlo[db], dhi[db]);
+        }
 #pragma unroll
         for (int qblk = 0; qblk < 2; ++qblk) {
             f32x16_t s, dp;
 #pragma unroll
-            for (int e = 0; e < 16; ++e) s[e] = dp[e] = 0.f;
-#pragma unroll
-            for (int ks = 0; ks < C::KS; ++ks) {
-                s = mfma32(row_frag<HD>(ql, qblk * 32 + r, ks * 2 + h2), kf[ks], s);
-                dp = mfma32(row_frag<HD>(dol, qblk * 32 + r, ks * 2 + h2), vf[ks], dp);
-            }
-#pragma unroll
             for (int t = 0; t < 4; ++t) {
                 const float4 l4 = *reinterpret_cast<const float4*>(lsl + qblk * 32 + 8 * t + 4 * h2);
                 const float4 d4 = *reinterpret_cast<const float4*>(dll + qblk * 32 + 8 * t + 4 * h2);
-                const float la[4] = {l4.x, l4.y, l4.z, l4.w}, da[4] = {d4.x, d4.y, d4.z, d4.w};
+                s[4 * t] = l4.x; s[4 * t + 1] = l4.y; s[4 * t + 2] = l4.z; s[4 * t + 3] = l4.w;
+                dp[4 * t] = d4.x; dp[4 * t + 1] = d4.y; dp[4 * t + 2] = d4.z; dp[4 * t + 3] = d4.w;
+            }
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(s[4 * t + e], c, -la[e]));
-                    s[4 * t + e] = pv;
-                    dp[4 * t + e] = pv * (dp[4 * t + e] - da[e]);
+            for (int ks = 0; ks < C::KS; ++ks) {
+                s = mfma32(*reinterpret_cast<const short8_t*>(ql + koff[ks] + qblk * 32 * C::RB), kf[ks], s);
+                dp = mfma32(*reinterpret_cast<const short8_t*>(dol + koff[ks] + qblk * 32 * C::RB), vf[ks], dp);
+            }
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                s[e] = __builtin_amdgcn_exp2f(s[e] * c);
+                dp[e] *= s[e];
+            }
+            if (qblk == 0) {
+#pragma unroll
+                for (int db = 0; db < C::DB; ++db) {
+                    tr_wait(qlo[db], qhi[db]);
+                    tr_wait(dlo[db], dhi[db]);
                 }
             }
 #pragma unroll
@@ -450,14 +652,13 @@ __global__ __launch_bounds__(AT) void attn_bwd_dkv_bf16_kernel(const bf16_t* __r
                 const bf16x8_t pf = cvt8(s, s2), dsf = cvt8(dp, s2);
 #pragma unroll
                 for (int db = 0; db < C::DB; ++db) {
-                    dv[db] = mfma32(tr_frag<HD>(dot, qblk * 32, s2, db, lane), pf, dv[db]);
-                    dk[db] = mfma32(tr_frag<HD>(qt, qblk * 32, s2, db, lane), dsf, dk[db]);
+                    dv[db] = mfma32(join8(dlo[db][qblk * 2 + s2], dhi[db][qblk * 2 + s2]), pf, dv[db]);
+                    dk[db] = mfma32(join8(qlo[db][qblk * 2 + s2], qhi[db][qblk * 2 + s2]), dsf, dk[db]);
                 }
             }
         }
-        if (it + 1 < nt) stash(smem + ((it + 1) & 1) * STAGE);
-        __syncthreads();
     }
+    __syncthreads();
     bf16_t* dkb = dqkv + ((int64_t)nb * L + k0) * rs + H * HD + h * HD;
     store_T<HD>(dk, scale, smem + wave * 32 * C::RB, dkb, rs, L - k0, lane);
     store_T<HD>(dv, 1.0f, smem + (4 + wave) * 32 * C::RB, dkb + H * HD, rs, L - k0, lane);
@@ -627,21 +828,23 @@ template <typename K> static int set_lds(K kernel, size_t bytes) {
 
 template <int HD>
 static int fwd_bf16(const void* qkv, void* out, float* lse, int NB, int L, int H, float c, hipStream_t s) {
-    const size_t lds = 4 * ACfg<HD>::TILE;
+    const size_t lds = 3 * (2 * ACfg<HD>::TILE + (HD == 16 ? 2048 : 0));
     if (int rc = set_lds(attn_fwd_bf16_kernel<HD>, lds)) return rc;
     hipLaunchKernelGGL(attn_fwd_bf16_kernel<HD>, dim3(cdiv(L, 128), H, NB), dim3(AT), lds, s, (const bf16_t*)qkv, (bf16_t*)out, lse, L, H, c);
     return 0;
 }
 template <int HD>
-static int bwd_bf16(const void* qkv, const void* dout, const float* lse, const float* delta, void* dqkv, int NB, int L, int H, float c,
+static int bwd_bf16(const void* qkv, const void* dout, const float* lse, const float* ws, void* dqkv, int NB, int L, int H, float c,
                     float scale, hipStream_t s) {
-    const size_t lds_q = 6 * ACfg<HD>::TILE;
-    const size_t lds_kv = 2 * (4 * ACfg<HD>::TILE + 512);
+    const float* delta = ws;                           // negated
+    const float* nlsc = ws + (int64_t)NB * H * L;
+    const size_t lds_q = 3 * 2 * ACfg<HD>::TILE;
+    const size_t lds_kv = 3 * (2 * ACfg<HD>::TILE + 512);
     if (int rc = set_lds(attn_bwd_dq_bf16_kernel<HD>, lds_q)) return rc;
     if (int rc = set_lds(attn_bwd_dkv_bf16_kernel<HD>, lds_kv)) return rc;
     hipLaunchKernelGGL(attn_bwd_dq_bf16_kernel<HD>, dim3(cdiv(L, 128), H, NB), dim3(AT), lds_q, s, (const bf16_t*)qkv, (const bf16_t*)dout, lse,
                        delta, (bf16_t*)dqkv, L, H, c, scale);
-    hipLaunchKernelGGL(attn_bwd_dkv_bf16_kernel<HD>, dim3(cdiv(L, 128), H, NB), dim3(AT), lds_kv, s, (const bf16_t*)qkv, (const bf16_t*)dout, lse,
+    hipLaunchKernelGGL(attn_bwd_dkv_bf16_kernel<HD>, dim3(cdiv(L, 128), H, NB), dim3(AT), lds_kv, s, (const bf16_t*)qkv, (const bf16_t*)dout, nlsc,
                        delta, (bf16_t*)dqkv, L, H, c, scale);
     return 0;
 }
@@ -696,13 +899,13 @@ extern "C" int star_attn_bwd(const void* qkv, const void* out, const void* dout,
     const int64_t items = (int64_t)NB * L * H;
     int rc = 0;
     if (dt == STAR_BF16) {
-        hipLaunchKernelGGL(attn_delta_kernel<bf16_t>, dim3(cdiv(items, 256)), dim3(256), 0, s, (const bf16_t*)out, (const bf16_t*)dout, delta, NB, L, H, hd);
+        hipLaunchKernelGGL((attn_delta_kernel<bf16_t, true>), dim3(cdiv(items, 256)), dim3(256), 0, s, (const bf16_t*)out, (const bf16_t*)dout, lse, delta, NB, L, H, hd, 1.0f / c);
         STAR_LAUNCH_CHECK("star_attn_bwd(delta)");
         if (hd == 16) rc = bwd_bf16<16>(qkv, dout, lse, delta, dqkv, NB, L, H, c, scale, s);
         else if (hd == 32) rc = bwd_bf16<32>(qkv, dout, lse, delta, dqkv, NB, L, H, c, scale, s);
         else rc = bwd_bf16<64>(qkv, dout, lse, delta, dqkv, NB, L, H, c, scale, s);
     } else {
-        hipLaunchKernelGGL(attn_delta_kernel<float>, dim3(cdiv(items, 256)), dim3(256), 0, s, (const float*)out, (const float*)dout, delta, NB, L, H, hd);
+        hipLaunchKernelGGL((attn_delta_kernel<float, false>), dim3(cdiv(items, 256)), dim3(256), 0, s, (const float*)out, (const float*)dout, lse, delta, NB, L, H, hd, 1.0f / c);
         STAR_LAUNCH_CHECK("star_attn_bwd(delta)");
         if (hd == 16) bwd_f32<16>(qkv, dout, lse, delta, dqkv, NB, L, H, c, scale, s);
         else if (hd == 32) bwd_f32<32>(qkv, dout, lse, delta, dqkv, NB, L, H, c, scale, s);

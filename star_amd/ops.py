@@ -216,7 +216,7 @@ def attn_bwd(qkv, out, dout, lse, nb, l, h, hd):
     dt = L.dt_of(qkv)
     assert qkv.is_contiguous() and out.is_contiguous() and dout.is_contiguous() and dout.dtype == qkv.dtype
     dqkv = torch.empty_like(qkv)
-    delta = torch.empty(nb, h, l, dtype=torch.float32, device=qkv.device)
+    delta = torch.empty(2, nb, h, l, dtype=torch.float32, device=qkv.device)   # workspace: delta | scaled lse
     with _timed("attn_bwd", 10.0 * nb * h * l * l * hd):
         L.check(L.lib().star_attn_bwd(p(qkv), p(out), p(dout), p(lse), p(delta), p(dqkv), nb, l, h, hd, dt, L.stream()))
     return dqkv
