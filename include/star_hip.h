@@ -96,9 +96,9 @@ typedef struct StarGemm {
     int32_t res_mod;        /* >0: residual row = destination row % res_mod */
     const float* res2;      /* optional float32 [res2_div-indexed rows, N]: row = (m / res2_div) % res2_mod */
     int32_t res2_div, res2_mod;
-    const void* aux;        /* optional dt [M, N] used by ACT_DGELU / ACT_DRELU (pre-activation / output) */
+    const void* aux;        /* optional dt [M, N] used by ACT_DGELU / ACT_DRELU (pre-activation / output) / ACT_MULAUX */
     int32_t act;            /* STAR_ACT_* */
-    void* pre;              /* optional dt [M, N]: value before the activation */
+    void* pre;              /* optional dt [M, N]: value before the activation (or its derivative: PRE_IS_GRAD) */
     void* out_lp;           /* optional dt [M(dest), N] */
     float* out_f32;         /* optional float32 [M(dest), N] */
     int32_t M, N, K;
@@ -107,11 +107,14 @@ typedef struct StarGemm {
 } StarGemm;
 #define STAR_GEMM_RES_BY_AROW 1 /* residual row = A row % res_mod, and rows with a_rows[m] < 0 are written as zeros
                                    (encode_partial: the patch embedding of a zero-padded slot is a zero row) */
+#define STAR_GEMM_PRE_IS_GRAD 2 /* with ACT_GELU / ACT_RELU: `pre` receives act'(pre-activation), the factor the backward
+                                   pass multiplies by (ACT_MULAUX), instead of the pre-activation itself */
 #define STAR_ACT_NONE 0
 #define STAR_ACT_GELU 1   /* exact erf GELU (timm Mlp act_layer=nn.GELU) */
 #define STAR_ACT_RELU 2   /* compressor ReLU (mae_base.py:284-287) */
 #define STAR_ACT_DGELU 3  /* backward: multiply by gelu'(aux) */
 #define STAR_ACT_DRELU 4  /* backward: multiply by (aux > 0) */
+#define STAR_ACT_MULAUX 5 /* backward: multiply by aux (a derivative stored by the forward, see STAR_GEMM_PRE_IS_GRAD) */
 int star_gemm(const StarGemm* g, void* stream);
 
 /* Weight gradient: dW[n, k] = sum_m dY[m, n] * X[xrow(m), k]  (float32, written), optional

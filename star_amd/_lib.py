@@ -10,11 +10,12 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libstar_hip.so")
+LIB_PATH = os.environ.get("STAR_HIP_LIB") or os.path.join(_HERE, "libstar_hip.so")   # override: A/B builds of the kernels
 
 BF16, F32 = 0, 1
-ACT_NONE, ACT_GELU, ACT_RELU, ACT_DGELU, ACT_DRELU = 0, 1, 2, 3, 4
+ACT_NONE, ACT_GELU, ACT_RELU, ACT_DGELU, ACT_DRELU, ACT_MULAUX = 0, 1, 2, 3, 4, 5
 GEMM_RES_BY_AROW = 1
+GEMM_PRE_IS_GRAD = 2
 
 _lib = None
 

@@ -227,12 +227,16 @@ __global__ __launch_bounds__(AT) void attn_fwd_bf16_kernel(const bf16_t* __restr
     constexpr int NI = 2 * C::NP / 4;                           // DMA instructions per wave per tile
     constexpr int STAGE = 2 * C::TILE + (HD == 16 ? 2048 : 0);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int h = blockIdx.y, nb = blockIdx.z;
+    // XCD-aware work order: the L/128 row blocks of one (sequence, head) stream the same K/V (Q/dO) tiles, so they
+    // run back to back on ONE XCD and share its L2 instead of fetching the tiles into all eight
+    const int nrb = (L + 127) >> 7;
+    const int work = xcd_remap(blockIdx.x, gridDim.x);
+    const int rblk = work % nrb, h = (work / nrb) % H, nb = work / (nrb * H);
     const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h2 = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int64_t rs = (int64_t)3 * H * HD;
     const bf16_t* qb = qkv + (int64_t)nb * L * rs + h * HD;
-    const int q0 = blockIdx.x * 128 + wave * 32;
+    const int q0 = rblk * 128 + wave * 32;
     const int q = q0 + r;
 
     short8_t qf[C::KS];
@@ -415,12 +419,16 @@ __global__ __launch_bounds__(AT) void attn_bwd_dq_bf16_kernel(const bf16_t* __re
     constexpr int NI = 2 * C::NP / 4;
     constexpr int STAGE = 2 * C::TILE;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int h = blockIdx.y, nb = blockIdx.z;
+    // XCD-aware work order: the L/128 row blocks of one (sequence, head) stream the same K/V (Q/dO) tiles, so they
+    // run back to back on ONE XCD and share its L2 instead of fetching the tiles into all eight
+    const int nrb = (L + 127) >> 7;
+    const int work = xcd_remap(blockIdx.x, gridDim.x);
+    const int rblk = work % nrb, h = (work / nrb) % H, nb = work / (nrb * H);
     const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h2 = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int64_t rs = (int64_t)3 * H * HD;
     const bf16_t* qb = qkv + (int64_t)nb * L * rs + h * HD;
-    const int q0 = blockIdx.x * 128 + wave * 32;
+    const int q0 = rblk * 128 + wave * 32;
     const int q = q0 + r;
     short8_t qf[C::KS], dof[C::KS];
     float ls = INFINITY, ndl = 0.f;
@@ -531,13 +539,17 @@ __global__ __launch_bounds__(AT) void attn_bwd_dkv_bf16_kernel(const bf16_t* __r
     constexpr int NI = 2 * C::NP / 4;
     constexpr int STAGE = 2 * C::TILE + 512;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int h = blockIdx.y, nb = blockIdx.z;
+    // XCD-aware work order: the L/128 row blocks of one (sequence, head) stream the same K/V (Q/dO) tiles, so they
+    // run back to back on ONE XCD and share its L2 instead of fetching the tiles into all eight
+    const int nrb = (L + 127) >> 7;
+    const int work = xcd_remap(blockIdx.x, gridDim.x);
+    const int rblk = work % nrb, h = (work / nrb) % H, nb = work / (nrb * H);
     const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h2 = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int64_t rs = (int64_t)3 * H * HD, ro = (int64_t)H * HD;
     const bf16_t* qb = qkv + (int64_t)nb * L * rs + h * HD;
     const bf16_t* dob = dout + (int64_t)nb * L * ro + h * HD;
-    const int k0 = blockIdx.x * 128 + wave * 32;
+    const int k0 = rblk * 128 + wave * 32;
     const int key = k0 + r;
     short8_t kf[C::KS], vf[C::KS];
 #pragma unroll
@@ -830,7 +842,7 @@ template <int HD>
 static int fwd_bf16(const void* qkv, void* out, float* lse, int NB, int L, int H, float c, hipStream_t s) {
     const size_t lds = 3 * (2 * ACfg<HD>::TILE + (HD == 16 ? 2048 : 0));
     if (int rc = set_lds(attn_fwd_bf16_kernel<HD>, lds)) return rc;
-    hipLaunchKernelGGL(attn_fwd_bf16_kernel<HD>, dim3(cdiv(L, 128), H, NB), dim3(AT), lds, s, (const bf16_t*)qkv, (bf16_t*)out, lse, L, H, c);
+    hipLaunchKernelGGL(attn_fwd_bf16_kernel<HD>, dim3(cdiv(L, 128) * H * NB), dim3(AT), lds, s, (const bf16_t*)qkv, (bf16_t*)out, lse, L, H, c);
     return 0;
 }
 template <int HD>
@@ -842,9 +854,9 @@ static int bwd_bf16(const void* qkv, const void* dout, const float* lse, const f
     const size_t lds_kv = 3 * (2 * ACfg<HD>::TILE + 512);
     if (int rc = set_lds(attn_bwd_dq_bf16_kernel<HD>, lds_q)) return rc;
     if (int rc = set_lds(attn_bwd_dkv_bf16_kernel<HD>, lds_kv)) return rc;
-    hipLaunchKernelGGL(attn_bwd_dq_bf16_kernel<HD>, dim3(cdiv(L, 128), H, NB), dim3(AT), lds_q, s, (const bf16_t*)qkv, (const bf16_t*)dout, lse,
+    hipLaunchKernelGGL(attn_bwd_dq_bf16_kernel<HD>, dim3(cdiv(L, 128) * H * NB), dim3(AT), lds_q, s, (const bf16_t*)qkv, (const bf16_t*)dout, lse,
                        delta, (bf16_t*)dqkv, L, H, c, scale);
-    hipLaunchKernelGGL(attn_bwd_dkv_bf16_kernel<HD>, dim3(cdiv(L, 128), H, NB), dim3(AT), lds_kv, s, (const bf16_t*)qkv, (const bf16_t*)dout, nlsc,
+    hipLaunchKernelGGL(attn_bwd_dkv_bf16_kernel<HD>, dim3(cdiv(L, 128) * H * NB), dim3(AT), lds_kv, s, (const bf16_t*)qkv, (const bf16_t*)dout, nlsc,
                        delta, (bf16_t*)dqkv, L, H, c, scale);
     return 0;
 }
@@ -865,7 +877,7 @@ static int attn_check(const char* who, int NB, int L, int H, int hd, int dt) {
     STAR_CHECK(NB > 0 && L > 0 && H > 0, "%s: bad shape NB=%d L=%d H=%d", who, NB, L, H);
     STAR_CHECK(hd == 16 || hd == 32 || hd == 64, "%s: head dim %d not in {16,32,64}", who, hd);
     STAR_CHECK(dt == STAR_BF16 || dt == STAR_F32, "%s: unknown dtype %d", who, dt);
-    STAR_CHECK(H <= 65535 && NB <= 65535, "%s: H, NB too large for the grid", who);
+    STAR_CHECK(H <= 65535 && NB <= 65535 && (int64_t)cdiv(L, 128) * H * NB < (1ll << 31), "%s: H, NB, L too large for the grid", who);
     return 0;
 }
 

@@ -24,12 +24,12 @@ typedef unsigned short bf16_t;  // raw bf16 bits
 
 __device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((unsigned)v) << 16); }
 
-// round-to-nearest-even; NaN stays NaN (plain cast path of the compiler)
-__device__ __forceinline__ bf16_t f2bf(float f) {
-    unsigned u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (bf16_t)(u >> 16);
+// round-to-nearest-even, NaN stays NaN: gfx950 has the conversion in hardware (v_cvt_pk_bf16_f32)
+__device__ __forceinline__ bf16_t f2bf(float f) { return __builtin_bit_cast(bf16_t, (__bf16)f); }
+__device__ __forceinline__ unsigned pack_bf16(float lo, float hi) {
+    typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+    typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+    return __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2_t){lo, hi}, bf16x2_t));
 }
 
 template <typename T> struct Act;
@@ -57,9 +57,39 @@ __device__ __forceinline__ void st4(float* p, const float (&v)[4]) {
 }
 __device__ __forceinline__ void st4(bf16_t* p, const float (&v)[4]) {
     uint2 t;
-    t.x = (unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16);
-    t.y = (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16);
+    t.x = pack_bf16(v[0], v[1]);
+    t.y = pack_bf16(v[2], v[3]);
     *reinterpret_cast<uint2*>(p) = t;
+}
+// 16-wide runs (16-byte vector accesses)
+__device__ __forceinline__ void ld16(const float* p, float (&v)[16]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float4 t = reinterpret_cast<const float4*>(p)[i];
+        v[4 * i] = t.x; v[4 * i + 1] = t.y; v[4 * i + 2] = t.z; v[4 * i + 3] = t.w;
+    }
+}
+__device__ __forceinline__ void ld16(const bf16_t* p, float (&v)[16]) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const uint4 t = reinterpret_cast<const uint4*>(p)[i];
+        const unsigned w[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            v[8 * i + 2 * k] = __uint_as_float(w[k] << 16);
+            v[8 * i + 2 * k + 1] = __uint_as_float(w[k] & 0xffff0000u);
+        }
+    }
+}
+__device__ __forceinline__ void st16(float* p, const float (&v)[16]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) reinterpret_cast<float4*>(p)[i] = make_float4(v[4 * i], v[4 * i + 1], v[4 * i + 2], v[4 * i + 3]);
+}
+__device__ __forceinline__ void st16(bf16_t* p, const float (&v)[16]) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+        reinterpret_cast<uint4*>(p)[i] = make_uint4(pack_bf16(v[8 * i], v[8 * i + 1]), pack_bf16(v[8 * i + 2], v[8 * i + 3]),
+                                                    pack_bf16(v[8 * i + 4], v[8 * i + 5]), pack_bf16(v[8 * i + 6], v[8 * i + 7]));
 }
 
 __device__ __forceinline__ float wave_sum(float v) {
@@ -71,6 +101,13 @@ __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
     return v;
+}
+
+// Workgroups are dealt to the 8 XCDs round-robin (block b runs on XCD b % 8, each with its own L2).  This maps
+// the launch index to a work index such that every XCD walks a CONTIGUOUS range of work items (bijective).
+__device__ __forceinline__ int xcd_remap(int bid, int nblk) {
+    const int q = nblk >> 3, r = nblk & 7, x = bid & 7, i = bid >> 3;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
 }
 
 static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }

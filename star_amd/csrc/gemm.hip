@@ -29,12 +29,6 @@ typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 
 #define GT 256  // threads
 
-__device__ __forceinline__ int xcd_remap(int bid, int nblk) {
-    // blocks b, b+8, ... share an XCD; give each XCD a contiguous chunk of tile ids (bijective)
-    const int q = nblk >> 3, r = nblk & 7, x = bid & 7, i = bid >> 3;
-    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
-}
-
 // erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7, i.e. float32 round-off level) on the v_rcp / v_exp units:
 // about a dozen VALU instructions instead of libm's ~50, which matters because the GELU epilogue of a
 // 128x128 tile with K = 384 would otherwise cost more cycles than the tile's MFMAs.
@@ -50,6 +44,21 @@ __device__ __forceinline__ float erf_as(float x) {
     return copysignf(r, x);
 }
 __device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erf_as(x * 0.70710678118654752f)); }
+// gelu(u) and gelu'(u) together: the derivative reuses Phi(u) and exp(-u^2/2) of the erf evaluation (3 extra
+// instructions), so the backward pass multiplies by a stored factor instead of evaluating erf again
+__device__ __forceinline__ void gelu_both(float u, float& v, float& dv) {
+    const float z = fabsf(u) * 0.70710678118654752f;
+    const float t = __builtin_amdgcn_rcpf(__builtin_fmaf(0.3275911f, z, 1.0f));
+    float p = __builtin_fmaf(1.061405429f, t, -1.453152027f);
+    p = __builtin_fmaf(p, t, 1.421413741f);
+    p = __builtin_fmaf(p, t, -0.284496736f);
+    p = __builtin_fmaf(p, t, 0.254829592f);
+    const float e = __builtin_amdgcn_exp2f(-1.4426950408889634f * z * z);   // exp(-u^2 / 2)
+    const float hy = 0.5f * p * t * e;                                      // erfc(|u| / sqrt 2) / 2
+    const float phi = u >= 0.f ? 1.0f - hy : hy;
+    v = u * phi;
+    dv = __builtin_fmaf(u * 0.3989422804014327f, e, phi);
+}
 __device__ __forceinline__ float dgelu_f(float x) {
     return 0.5f * (1.0f + erf_as(x * 0.70710678118654752f)) + x * 0.3989422804014327f * __builtin_amdgcn_exp2f(-0.72134752044448170f * x * x);
 }
@@ -210,11 +219,18 @@ __global__ __launch_bounds__(GT) void gemm_nt_kernel(const StarGemm g) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] += t[e];
             }
-            if (pre) st4(pre + (size_t)d * N + n0, v);
+            const bool pre_grad = (g.flags & STAR_GEMM_PRE_IS_GRAD) != 0;
+            if (pre && !pre_grad) st4(pre + (size_t)d * N + n0, v);
             if (g.act == STAR_ACT_GELU) {
+                float dv[4];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = gelu_f(v[e]);
+                for (int e = 0; e < 4; ++e) gelu_both(v[e], v[e], dv[e]);
+                if (pre && pre_grad) st4(pre + (size_t)d * N + n0, dv);
             } else if (g.act == STAR_ACT_RELU) {
+                if (pre && pre_grad) {
+                    const float dv[4] = {v[0] > 0.f ? 1.f : 0.f, v[1] > 0.f ? 1.f : 0.f, v[2] > 0.f ? 1.f : 0.f, v[3] > 0.f ? 1.f : 0.f};
+                    st4(pre + (size_t)d * N + n0, dv);
+                }
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
             } else if (g.act == STAR_ACT_DGELU) {
@@ -222,6 +238,11 @@ __global__ __launch_bounds__(GT) void gemm_nt_kernel(const StarGemm g) {
                 ld4(aux + (size_t)m * N + n0, t);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] *= dgelu_f(t[e]);
+            } else if (g.act == STAR_ACT_MULAUX) {
+                float t[4];
+                ld4(aux + (size_t)m * N + n0, t);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] *= t[e];
             } else if (g.act == STAR_ACT_DRELU) {
                 float t[4];
                 ld4(aux + (size_t)m * N + n0, t);
@@ -263,8 +284,14 @@ __global__ __launch_bounds__(GT) void gemm_nt_kernel(const StarGemm g) {
 #define NTF_BK 32
 __device__ __forceinline__ int ntf_swz(int row) { return (0x78 >> (((row >> 2) & 3) << 1)) & 3; }
 
-template <int NST>
-__global__ __launch_bounds__(GT) void gemm_nt_fast_kernel(const StarGemm g) {
+// EPI specialises the epilogue at compile time (the fully general one costs ~10k instructions and spills):
+#define EPI_GENERIC 0   // everything decided at run time
+#define EPI_LINEAR 1    // bias only (any row gather / scatter); no activation, residual, aux, pre
+#define EPI_RES 2       // bias + one float32 residual table; no activation
+#define EPI_GELU_GRAD 3 // bias + GELU, `pre` receives gelu' (STAR_GEMM_PRE_IS_GRAD)
+#define EPI_MULAUX 4    // times aux; no bias, no residual
+template <int NST, int EPI>
+__global__ __launch_bounds__(GT) __attribute__((amdgpu_waves_per_eu(3))) void gemm_nt_fast_kernel(const StarGemm g) {
     constexpr int BM = 128, BN = 128, STAGE = (BM + BN) * 64, PF = NST - 1;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int M = g.M, N = g.N, K = g.K;
@@ -284,7 +311,10 @@ __global__ __launch_bounds__(GT) void gemm_nt_fast_kernel(const StarGemm g) {
     for (int j = 0; j < 2; ++j) {
         const int r = wave * 32 + j * 16 + (lane >> 2);
         const int c = (lane & 3) ^ ntf_swz(r);
-        const int m = m_blk + r, n = n_blk + r;
+        // the W image holds row pi(r) at LDS row r, pi = swap of the bit fields [5:4] and [3:2]: MFMA block a,
+        // accumulator register j of lane group lg then is output column lg*16 + a*4 + j -- 16 CONTIGUOUS columns
+        // per lane, so the epilogue stores whole 32/64-byte runs straight from the registers (no LDS staging)
+        const int m = m_blk + r, n = n_blk + ((r & ~63) | ((r & 0x0c) << 2) | ((r & 0x30) >> 2) | (r & 3));
         long long src = -1;
         if (m < M) src = g.a_rows ? (long long)g.a_rows[m] : (long long)m;
         offA[j] = src >= 0 ? (unsigned)(src * K * 2 + c * 16) : 0x7fffffffu;
@@ -326,110 +356,180 @@ __global__ __launch_bounds__(GT) void gemm_nt_fast_kernel(const StarGemm g) {
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
+#ifndef GEMM_NODMA
         if (kt + PF < nk) issue(kt + PF);
+#endif
         const unsigned char* st = smem + (kt % NST) * STAGE;
         short8_t w8[4], x8[4];
 #pragma unroll
         for (int a = 0; a < 4; ++a) w8[a] = *reinterpret_cast<const short8_t*>(st + fw[a]);
 #pragma unroll
         for (int b = 0; b < 4; ++b) x8[b] = *reinterpret_cast<const short8_t*>(st + fx[b]);
+#ifdef GEMM_NOMFMA
+#pragma unroll
+        for (int a = 0; a < 4; ++a) asm volatile("" :: "v"(w8[a]), "v"(x8[a]));
+#else
 #pragma unroll
         for (int a = 0; a < 4; ++a)
 #pragma unroll
             for (int b = 0; b < 4; ++b)
                 acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, w8[a]), __builtin_bit_cast(bf16x8_t, x8[b]),
                                                                     acc[a][b], 0, 0, 0);
+#endif
     }
 
-    // ---- epilogue through LDS: two halves of 64 rows, fp32 [64][132]
-    float* stg = reinterpret_cast<float*>(smem);
-    constexpr int LDP = 132;
+    // ---- epilogue straight from the accumulators: lane (lr, lg) owns rows wm*64 + b*16 + lr (b = 0..3) and the 16
+    // contiguous columns n0 .. n0+15; a 16-lane group covers 16 rows x 64 (bf16: 32) bytes per store instruction
     bf16_t* out_lp = (bf16_t*)g.out_lp;
     bf16_t* pre = (bf16_t*)g.pre;
     const bf16_t* aux = (const bf16_t*)g.aux;
-    const bool by_arow = (g.flags & STAR_GEMM_RES_BY_AROW) != 0;
-    const int col4 = (tid & 31) << 2, rsub = tid >> 5;
-    const int n0 = n_blk + col4;
-    float bias4[4] = {0.f, 0.f, 0.f, 0.f};
-    if (g.bias && n0 < N) ld4(g.bias + n0, bias4);
-#pragma unroll 1
-    for (int half = 0; half < 2; ++half) {
-        __syncthreads();   // operand ring (or the previous half) fully consumed
-        if (wm == half) {
+    constexpr bool GEN = EPI == EPI_GENERIC;
+    const bool by_arow = (EPI == EPI_GENERIC || EPI == EPI_RES) && (g.flags & STAR_GEMM_RES_BY_AROW) != 0;
+    const bool pre_grad = GEN ? (g.flags & STAR_GEMM_PRE_IS_GRAD) != 0 : true;
+    const bool has_pre = GEN ? pre != nullptr : EPI == EPI_GELU_GRAD;
+    const bool has_bias = EPI == EPI_MULAUX ? false : g.bias != nullptr;
+    const bool has_res = GEN ? g.res != nullptr : EPI == EPI_RES;
+    const bool has_res2 = GEN && g.res2 != nullptr;
+    const int act = GEN ? g.act : (EPI == EPI_GELU_GRAD ? STAR_ACT_GELU : (EPI == EPI_MULAUX ? STAR_ACT_MULAUX : STAR_ACT_NONE));
+    const int n0 = n_blk + wn * 64 + lg * 16;
+    if (n0 >= N) return;   // N % 16 == 0 on this path: a lane's 16 columns are all in or all out
+    float bias16[16];
 #pragma unroll
-            for (int b = 0; b < 4; ++b)
+    for (int e = 0; e < 16; ++e) bias16[e] = 0.f;
+    if (has_bias) ld16(g.bias + n0, bias16);
+    // The output may alias the residual (x += ...), so the compiler keeps every row group's reads behind the previous
+    // group's stores and each group would pay a full memory round trip.  Reads are therefore issued by hand two row
+    // groups ahead of their use (pf ring), the row indices for all four groups first.
+    const bool use_aux = act == STAR_ACT_DGELU || act == STAR_ACT_MULAUX || act == STAR_ACT_DRELU;
+    int drow[4], arow[4];
 #pragma unroll
-                for (int a = 0; a < 4; ++a)
-                    *reinterpret_cast<f32x4_t*>(stg + (b * 16 + lr) * LDP + wn * 64 + a * 16 + lg * 4) = acc[a][b];
+    for (int b = 0; b < 4; ++b) {
+        const int m = m_blk + wm * 64 + b * 16 + lr;
+        drow[b] = -1;
+        arow[b] = -1;
+        if (m < M) {
+            drow[b] = g.c_rows ? g.c_rows[m] : m;
+            arow[b] = (by_arow && g.a_rows) ? g.a_rows[m] : drow[b];
         }
-        __syncthreads();
-#pragma unroll 2
-        for (int i = 0; i < 8; ++i) {
-            const int row = rsub + 8 * i;
-            const int m = m_blk + half * 64 + row;
-            if (m >= M || n0 >= N) continue;
-            const long long d = g.c_rows ? (long long)g.c_rows[m] : (long long)m;
-            if (d < 0) continue;
-            const long long arow = (by_arow && g.a_rows) ? (long long)g.a_rows[m] : d;
-            float v[4];
-            ld4(stg + row * LDP + col4, v);
-            if (by_arow && arow < 0) {
-                const float z[4] = {0.f, 0.f, 0.f, 0.f};
-                if (out_lp) st4(out_lp + (size_t)d * N + n0, z);
-                if (g.out_f32) st4(g.out_f32 + (size_t)d * N + n0, z);
-                continue;
-            }
+    }
+    float pf[2][16];   // residual rows, or (when there is no residual) the aux rows
+    auto prefetch = [&](int b, float (&dst)[16]) {
+        const int m = m_blk + wm * 64 + b * 16 + lr;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] += bias4[e];
-            if (pre) st4(pre + (size_t)d * N + n0, v);
-            if (g.act == STAR_ACT_GELU) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = gelu_f(v[e]);
-            } else if (g.act == STAR_ACT_RELU) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
-            } else if (g.act == STAR_ACT_DGELU) {
-                float t[4];
-                ld4(aux + (size_t)m * N + n0, t);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] *= dgelu_f(t[e]);
-            } else if (g.act == STAR_ACT_DRELU) {
-                float t[4];
-                ld4(aux + (size_t)m * N + n0, t);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = t[e] > 0.f ? v[e] : 0.f;
-            }
-            if (g.res) {
-                const long long rb = by_arow ? arow : d;
-                const long long rr = g.res_mod > 0 ? rb % g.res_mod : rb;
-                float t[4];
-                ld4(g.res + (size_t)rr * N + n0, t);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] += t[e];
-            }
-            if (g.res2) {
-                const int rr = (m / g.res2_div) % g.res2_mod;
-                float t[4];
-                ld4(g.res2 + (size_t)rr * N + n0, t);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] += t[e];
-            }
-            if (out_lp) st4(out_lp + (size_t)d * N + n0, v);
-            if (g.out_f32) st4(g.out_f32 + (size_t)d * N + n0, v);
+        for (int e = 0; e < 16; ++e) dst[e] = 0.f;
+        if (drow[b] < 0 || (by_arow && arow[b] < 0)) return;
+        if (has_res) {
+            const long long rb = by_arow ? arow[b] : drow[b];
+            ld16(g.res + (size_t)(g.res_mod > 0 ? rb % g.res_mod : rb) * N + n0, dst);
+        } else if (use_aux) {
+            ld16(aux + (size_t)m * N + n0, dst);
         }
+    };
+    if (has_res || use_aux) {
+        prefetch(0, pf[0]);
+        prefetch(1, pf[1]);
+    }
+    // arithmetic and stores, in place in the accumulator registers
+#pragma unroll
+    for (int bb = 0; bb < 4; ++bb)
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[a][bb][j] += bias16[a * 4 + j];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        const int m = m_blk + wm * 64 + b * 16 + lr;
+        const long long d = drow[b];
+        float cur[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) cur[e] = pf[b & 1][e];
+        if (b + 2 < 4 && (has_res || use_aux)) prefetch(b + 2, pf[b & 1]);
+        if (d < 0) continue;
+        float v[16];
+        if (by_arow && arow[b] < 0) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) v[e] = 0.f;
+            if (out_lp) st16(out_lp + (size_t)d * N + n0, v);
+            if (g.out_f32) st16(g.out_f32 + (size_t)d * N + n0, v);
+            continue;
+        }
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[a * 4 + j] = acc[a][b][j];
+        if (has_pre && !pre_grad) st16(pre + (size_t)d * N + n0, v);
+        if (act == STAR_ACT_GELU) {
+            if (has_pre && pre_grad) {
+                float dv[16];
+#pragma unroll
+                for (int e = 0; e < 16; ++e) gelu_both(v[e], v[e], dv[e]);
+                st16(pre + (size_t)d * N + n0, dv);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) v[e] = gelu_f(v[e]);
+            }
+        } else if (act == STAR_ACT_RELU) {
+            if (has_pre && pre_grad) {
+                float dv[16];
+#pragma unroll
+                for (int e = 0; e < 16; ++e) dv[e] = v[e] > 0.f ? 1.f : 0.f;
+                st16(pre + (size_t)d * N + n0, dv);
+            }
+#pragma unroll
+            for (int e = 0; e < 16; ++e) v[e] = fmaxf(v[e], 0.f);
+        } else if (use_aux) {
+            if (has_res) {   // both a residual and an activation gradient: the aux row was not prefetched
+                float t[16];
+                ld16(aux + (size_t)m * N + n0, t);
+#pragma unroll
+                for (int e = 0; e < 16; ++e)
+                    v[e] = act == STAR_ACT_DGELU ? v[e] * dgelu_f(t[e]) : (act == STAR_ACT_MULAUX ? v[e] * t[e] : (t[e] > 0.f ? v[e] : 0.f));
+            } else if (act == STAR_ACT_DGELU) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) v[e] *= dgelu_f(cur[e]);
+            } else if (act == STAR_ACT_MULAUX) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) v[e] *= cur[e];
+            } else {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) v[e] = cur[e] > 0.f ? v[e] : 0.f;
+            }
+        }
+        if (has_res) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) v[e] += cur[e];
+        }
+        if (has_res2) {
+            const int rr = (m / g.res2_div) % g.res2_mod;
+            float t2[16];
+            ld16(g.res2 + (size_t)rr * N + n0, t2);
+#pragma unroll
+            for (int e = 0; e < 16; ++e) v[e] += t2[e];
+        }
+        if (out_lp) st16(out_lp + (size_t)d * N + n0, v);
+        if (g.out_f32) st16(g.out_f32 + (size_t)d * N + n0, v);
     }
 }
 
-template <int NST>
-static int launch_nt_fast(const StarGemm* g, hipStream_t s) {
+template <int NST, int EPI>
+static void launch_nt_fast_epi(const StarGemm* g, hipStream_t s) {
     const int tiles = cdiv(g->M, 128) * cdiv(g->N, 128);
-    const size_t lds = (size_t)NST * 256 * 64;
+    const size_t lds = (size_t)NST * 256 * 64;   // the ring only: the epilogue does not stage through LDS
     static bool attr_done = false;
     if (!attr_done && lds > 48 * 1024) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_fast_kernel<NST>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_fast_kernel<NST, EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_done = true;
     }
-    hipLaunchKernelGGL((gemm_nt_fast_kernel<NST>), dim3(tiles), dim3(GT), lds, s, *g);
+    hipLaunchKernelGGL((gemm_nt_fast_kernel<NST, EPI>), dim3(tiles), dim3(GT), lds, s, *g);
+}
+template <int NST>
+static int launch_nt_fast(const StarGemm* g, hipStream_t s) {
+    const bool plain = !g->res2 && !g->aux && !g->pre && g->act == STAR_ACT_NONE;
+    if (plain && !g->res) launch_nt_fast_epi<NST, EPI_LINEAR>(g, s);
+    else if (plain) launch_nt_fast_epi<NST, EPI_RES>(g, s);
+    else if (g->act == STAR_ACT_GELU && g->pre && (g->flags & STAR_GEMM_PRE_IS_GRAD) && !g->res && !g->res2) launch_nt_fast_epi<NST, EPI_GELU_GRAD>(g, s);
+    else if (g->act == STAR_ACT_MULAUX && !g->bias && !g->res && !g->res2 && !g->pre) launch_nt_fast_epi<NST, EPI_MULAUX>(g, s);
+    else launch_nt_fast_epi<NST, EPI_GENERIC>(g, s);
     return 0;
 }
 
@@ -450,12 +550,12 @@ extern "C" int star_gemm(const StarGemm* g, void* stream) {
     STAR_CHECK(g->K % epc == 0, "star_gemm: K=%d must be a multiple of %d", g->K, epc);
     STAR_CHECK(g->N % 4 == 0, "star_gemm: N=%d must be a multiple of 4", g->N);
     STAR_CHECK(g->out_lp || g->out_f32 || g->pre, "star_gemm: no output");
-    STAR_CHECK(!(g->act == STAR_ACT_DGELU || g->act == STAR_ACT_DRELU) || g->aux, "star_gemm: activation gradient needs aux");
+    STAR_CHECK(!(g->act == STAR_ACT_DGELU || g->act == STAR_ACT_DRELU || g->act == STAR_ACT_MULAUX) || g->aux, "star_gemm: activation gradient needs aux");
     STAR_CHECK(!g->res2 || (g->res2_div > 0 && g->res2_mod > 0), "star_gemm: res2 needs div/mod");
     if (g->M == 0) return 0;
     hipStream_t s = (hipStream_t)stream;
     const bool narrow = g->N <= 32;
-    const bool fast_ok = g->dt == STAR_BF16 && !narrow && g->K % NTF_BK == 0 && (long long)g->N * g->K * 2 < 0x7fffffffLL &&
+    const bool fast_ok = g->dt == STAR_BF16 && !narrow && g->K % NTF_BK == 0 && g->N % 16 == 0 && (long long)g->N * g->K * 2 < 0x7fffffffLL &&
                          ((reinterpret_cast<uintptr_t>(g->A) | reinterpret_cast<uintptr_t>(g->W)) & 15) == 0;
     if (fast_ok) {
         launch_nt_fast<3>(g, s);

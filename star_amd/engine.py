@@ -14,7 +14,7 @@ import math
 import torch
 
 from . import ops
-from ._lib import ACT_DGELU, ACT_DRELU, ACT_GELU, ACT_NONE, ACT_RELU, BF16, F32, GEMM_RES_BY_AROW
+from ._lib import ACT_DRELU, ACT_GELU, ACT_MULAUX, ACT_NONE, ACT_RELU, BF16, F32, GEMM_PRE_IS_GRAD, GEMM_RES_BY_AROW
 
 _LINEARS_BLOCK = ("attn.qkv", "attn.proj", "mlp.fc1", "mlp.fc2")
 
@@ -122,7 +122,9 @@ def _block_fwd(x, P, W, pre, heads, nb, l, dt, eps, save, train):
     _, x_mid, _ = ops.gemm(a, _lin(P, W, pre + "attn.proj", dt), bias=P[pre + "attn.proj.bias"], res=x, want_lp=False,
                            want_f32=True, out_f32=None if train else x)
     h2, mean2, rstd2 = ops.layernorm_fwd(x_mid, P[pre + "norm2.weight"], P[pre + "norm2.bias"], eps, dt, want_stats=train)
-    v, _, u = ops.gemm(h2, _lin(P, W, pre + "mlp.fc1", dt), bias=P[pre + "mlp.fc1.bias"], act=ACT_GELU, want_pre=train)
+    # u is not the pre-activation but gelu'(pre-activation): all the backward needs of it (flag PRE_IS_GRAD)
+    v, _, u = ops.gemm(h2, _lin(P, W, pre + "mlp.fc1", dt), bias=P[pre + "mlp.fc1.bias"], act=ACT_GELU, want_pre=train,
+                       flags=GEMM_PRE_IS_GRAD)
     _, x_out, _ = ops.gemm(v, _lin(P, W, pre + "mlp.fc2", dt), bias=P[pre + "mlp.fc2.bias"], res=x_mid, want_lp=False,
                            want_f32=True, out_f32=None if train else x_mid)
     if train:
@@ -182,7 +184,7 @@ def _block_bwd(g, g_lp, s, P, W, dt, grads, G=None):
     heads, nb, l = s["heads"], s["nb"], s["l"]
     hd = s["x"].shape[1] // heads
     _wg(grads, G, pre + "mlp.fc2", g_lp, s["v"])
-    du, _, _ = ops.gemm(g_lp, _lin(P, W, pre + "mlp.fc2", dt, True), act=ACT_DGELU, aux=s["u"])
+    du, _, _ = ops.gemm(g_lp, _lin(P, W, pre + "mlp.fc2", dt, True), act=ACT_MULAUX, aux=s["u"])
     _wg(grads, G, pre + "mlp.fc1", du, s["h2"])
     dh2, _, _ = ops.gemm(du, _lin(P, W, pre + "mlp.fc1", dt, True))
     g1, g1_lp = _ln_bwd(grads, G, pre + "norm2", dh2, s["x_mid"], P, s["mean2"], s["rstd2"], g_in=g)

@@ -7,7 +7,7 @@ import numpy as np
 import torch
 
 from . import _lib as L
-from ._lib import ACT_DGELU, ACT_DRELU, ACT_GELU, ACT_NONE, ACT_RELU, BF16, F32, p  # noqa: F401
+from ._lib import ACT_DGELU, ACT_DRELU, ACT_GELU, ACT_MULAUX, ACT_NONE, ACT_RELU, BF16, F32, p  # noqa: F401
 
 
 class Profiler:

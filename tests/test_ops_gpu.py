@@ -16,7 +16,7 @@ pytestmark = pytest.mark.gpu
 if torch.cuda.is_available():
     from oracle import star_oracle as O
     from star_amd import ops
-    from star_amd._lib import ACT_DGELU, ACT_DRELU, ACT_GELU, ACT_NONE, ACT_RELU, BF16, F32
+    from star_amd._lib import ACT_DGELU, ACT_DRELU, ACT_GELU, ACT_MULAUX, ACT_NONE, ACT_RELU, BF16, F32, GEMM_PRE_IS_GRAD
 
 DEV = "cuda"
 
@@ -208,6 +208,17 @@ def test_gemm_epilogues(dt):
     torch.testing.assert_close(lp.double(), (a.double() @ w.double().t()) * ud.grad, **_tol(dt))
     lp, _, _ = ops.gemm(a, w, act=ACT_DRELU, aux=u)
     torch.testing.assert_close(lp.double(), (a.double() @ w.double().t()) * (u.double() > 0), **_tol(dt))
+    # the forward can store act'(pre-activation) instead (PRE_IS_GRAD); the backward then only multiplies (MULAUX)
+    lp, _, dpre = ops.gemm(a, w, bias=bias, act=ACT_GELU, want_pre=True, flags=GEMM_PRE_IS_GRAD)
+    bd = base.clone().requires_grad_(True)
+    torch.nn.functional.gelu(bd).sum().backward()
+    torch.testing.assert_close(lp.double(), torch.nn.functional.gelu(base), **_tol(dt))
+    torch.testing.assert_close(dpre.double(), bd.grad, **_tol(dt))
+    lp, _, dpre = ops.gemm(a, w, bias=bias, act=ACT_RELU, want_pre=True, flags=GEMM_PRE_IS_GRAD)
+    clear = base.abs() > 0.05
+    assert torch.equal(dpre.double()[clear], (base > 0).double()[clear])
+    lp, _, _ = ops.gemm(a, w, act=ACT_MULAUX, aux=u)
+    torch.testing.assert_close(lp.double(), (a.double() @ w.double().t()) * u.double(), **_tol(dt))
 
 
 @pytest.mark.parametrize("dt", [0, 1])

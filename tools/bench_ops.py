@@ -4,7 +4,7 @@ import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from star_amd import ops
-from star_amd._lib import ACT_GELU, ACT_DGELU, ACT_NONE
+from star_amd._lib import ACT_GELU, ACT_DGELU, ACT_MULAUX, ACT_NONE, GEMM_PRE_IS_GRAD
 
 dev = "cuda"
 M = int(os.environ.get("M", 40960))
@@ -29,13 +29,13 @@ def gemm_cases():
     for name, N, K, kw in [
         ("qkv      ", 1152, 384, dict(bias=True)),
         ("proj+res ", 384, 384, dict(bias=True, res=True)),
-        ("fc1+gelu ", 1536, 384, dict(bias=True, act=ACT_GELU, pre=True)),
+        ("fc1+gelu ", 1536, 384, dict(bias=True, act=ACT_GELU, pre=True, flags=GEMM_PRE_IS_GRAD)),
         ("fc2+res  ", 384, 1536, dict(bias=True, res=True)),
-        ("dfc2 dgel", 1536, 384, dict(act=ACT_DGELU, aux=True)),
+        ("dfc2 mula", 1536, 384, dict(act=ACT_MULAUX, aux=True)),
         ("dfc1     ", 384, 1536, dict()),
         ("dqkv     ", 384, 1152, dict()),
         ("dec qkv  ", 768, 256, dict(bias=True)),
-        ("dec fc1  ", 1024, 256, dict(bias=True, act=ACT_GELU, pre=True)),
+        ("dec fc1  ", 1024, 256, dict(bias=True, act=ACT_GELU, pre=True, flags=GEMM_PRE_IS_GRAD)),
         ("dec fc2  ", 256, 1024, dict(bias=True, res=True)),
         ("heads    ", 1664, 256, dict(bias=True, f32=True)),
     ]:
@@ -48,7 +48,7 @@ def gemm_cases():
         out32 = torch.empty(M, N, device=dev) if f32 else None
         outlp = None if f32 else torch.empty(M, N, device=dev, dtype=torch.bfloat16)
         fn = lambda: ops.gemm(a, w, bias=bias, act=kw.get("act", ACT_NONE), res=res, aux=aux, want_pre=bool(kw.get("pre")),
-                              want_lp=not f32, want_f32=f32, out_f32=out32, out_lp=outlp)
+                              want_lp=not f32, want_f32=f32, out_f32=out32, out_lp=outlp, flags=kw.get("flags", 0))
         us = timeit(fn)
         fl = 2.0 * M * N * K
         byt = M * K * 2 + M * N * ((4 if f32 else 2) + (2 if kw.get("pre") else 0) + (4 if kw.get("res") else 0) + (2 if kw.get("aux") else 0))
