@@ -8,6 +8,7 @@
 #include "../../include/star_hip.h"
 
 int star_set_error(int code, const char* fmt, ...);
+int star_num_cus();   // compute units of the current device (cached)
 
 #define STAR_CHECK(cond, ...)                                  \
     do {                                                       \

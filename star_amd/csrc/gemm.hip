@@ -295,9 +295,7 @@ __global__ __launch_bounds__(GT) __attribute__((amdgpu_waves_per_eu(3))) void ge
     constexpr int BM = 128, BN = 128, STAGE = (BM + BN) * 64, PF = NST - 1;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int M = g.M, N = g.N, K = g.K;
-    const int tiles_n = (N + BN - 1) / BN, tiles_m = (M + BM - 1) / BM;
-    const int tile = xcd_remap(blockIdx.x, tiles_m * tiles_n);
-    const int m_blk = (tile / tiles_n) * BM, n_blk = (tile % tiles_n) * BN;
+    const int tiles_n = (N + BN - 1) / BN, tiles_m = (M + BM - 1) / BM, ntiles = tiles_m * tiles_n;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave & 1, wn = wave >> 1;
@@ -307,19 +305,21 @@ __global__ __launch_bounds__(GT) __attribute__((amdgpu_waves_per_eu(3))) void ge
     __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g.A), 0, 0x7fffffff, 0x00020000);
     __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g.W), 0, 0x7fffffff, 0x00020000);
     unsigned offA[2], offW[2];
+    auto dma_setup = [&](int m_blk, int n_blk) {
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int r = wave * 32 + j * 16 + (lane >> 2);
-        const int c = (lane & 3) ^ ntf_swz(r);
-        // the W image holds row pi(r) at LDS row r, pi = swap of the bit fields [5:4] and [3:2]: MFMA block a,
-        // accumulator register j of lane group lg then is output column lg*16 + a*4 + j -- 16 CONTIGUOUS columns
-        // per lane, so the epilogue stores whole 32/64-byte runs straight from the registers (no LDS staging)
-        const int m = m_blk + r, n = n_blk + ((r & ~63) | ((r & 0x0c) << 2) | ((r & 0x30) >> 2) | (r & 3));
-        long long src = -1;
-        if (m < M) src = g.a_rows ? (long long)g.a_rows[m] : (long long)m;
-        offA[j] = src >= 0 ? (unsigned)(src * K * 2 + c * 16) : 0x7fffffffu;
-        offW[j] = n < N ? (unsigned)((long long)n * K * 2 + c * 16) : 0x7fffffffu;
-    }
+        for (int j = 0; j < 2; ++j) {
+            const int r = wave * 32 + j * 16 + (lane >> 2);
+            const int c = (lane & 3) ^ ntf_swz(r);
+            // the W image holds row pi(r) at LDS row r, pi = swap of the bit fields [5:4] and [3:2]: MFMA block a,
+            // accumulator register j of lane group lg then is output column lg*16 + a*4 + j -- 16 CONTIGUOUS columns
+            // per lane, so the epilogue stores whole 32/64-byte runs straight from the registers (no LDS staging)
+            const int m = m_blk + r, n = n_blk + ((r & ~63) | ((r & 0x0c) << 2) | ((r & 0x30) >> 2) | (r & 3));
+            long long src = -1;
+            if (m < M) src = g.a_rows ? (long long)g.a_rows[m] : (long long)m;
+            offA[j] = src >= 0 ? (unsigned)(src * K * 2 + c * 16) : 0x7fffffffu;
+            offW[j] = n < N ? (unsigned)((long long)n * K * 2 + c * 16) : 0x7fffffffu;
+        }
+    };
     auto issue = [&](int kt) {
         unsigned char* st = smem + (kt % NST) * STAGE;
         const unsigned kb = kt * (NTF_BK * 2);
@@ -331,13 +331,7 @@ __global__ __launch_bounds__(GT) __attribute__((amdgpu_waves_per_eu(3))) void ge
                                                      offW[j] + kb, 0, 0, 0);
         }
     };
-
-    f32x4_t acc[4][4];
-#pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int b = 0; b < 4; ++b) acc[a][b] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-    // fragment addresses inside a stage (constant over k-steps)
+    // fragment addresses inside a stage (constant over k-steps and tiles)
     int fw[4], fx[4];
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
@@ -345,41 +339,7 @@ __global__ __launch_bounds__(GT) __attribute__((amdgpu_waves_per_eu(3))) void ge
         fw[a] = BM * 64 + rw_ * 64 + ((lg ^ ntf_swz(rw_)) << 4);
         fx[a] = rx_ * 64 + ((lg ^ ntf_swz(rx_)) << 4);
     }
-
-    const int nk = K / NTF_BK;
-    for (int s0 = 0; s0 < PF && s0 < nk; ++s0) issue(s0);
-    for (int kt = 0; kt < nk; ++kt) {
-        const int rem = min(nk - 1 - kt, PF - 1);   // stages allowed to stay in flight behind stage kt
-        if (rem >= 3) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-        else if (rem == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        else if (rem == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-#ifndef GEMM_NODMA
-        if (kt + PF < nk) issue(kt + PF);
-#endif
-        const unsigned char* st = smem + (kt % NST) * STAGE;
-        short8_t w8[4], x8[4];
-#pragma unroll
-        for (int a = 0; a < 4; ++a) w8[a] = *reinterpret_cast<const short8_t*>(st + fw[a]);
-#pragma unroll
-        for (int b = 0; b < 4; ++b) x8[b] = *reinterpret_cast<const short8_t*>(st + fx[b]);
-#ifdef GEMM_NOMFMA
-#pragma unroll
-        for (int a = 0; a < 4; ++a) asm volatile("" :: "v"(w8[a]), "v"(x8[a]));
-#else
-#pragma unroll
-        for (int a = 0; a < 4; ++a)
-#pragma unroll
-            for (int b = 0; b < 4; ++b)
-                acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, w8[a]), __builtin_bit_cast(bf16x8_t, x8[b]),
-                                                                    acc[a][b], 0, 0, 0);
-#endif
-    }
-
-    // ---- epilogue straight from the accumulators: lane (lr, lg) owns rows wm*64 + b*16 + lr (b = 0..3) and the 16
-    // contiguous columns n0 .. n0+15; a 16-lane group covers 16 rows x 64 (bf16: 32) bytes per store instruction
+    // epilogue constants
     bf16_t* out_lp = (bf16_t*)g.out_lp;
     bf16_t* pre = (bf16_t*)g.pre;
     const bf16_t* aux = (const bf16_t*)g.aux;
@@ -391,123 +351,212 @@ __global__ __launch_bounds__(GT) __attribute__((amdgpu_waves_per_eu(3))) void ge
     const bool has_res = GEN ? g.res != nullptr : EPI == EPI_RES;
     const bool has_res2 = GEN && g.res2 != nullptr;
     const int act = GEN ? g.act : (EPI == EPI_GELU_GRAD ? STAR_ACT_GELU : (EPI == EPI_MULAUX ? STAR_ACT_MULAUX : STAR_ACT_NONE));
-    const int n0 = n_blk + wn * 64 + lg * 16;
-    if (n0 >= N) return;   // N % 16 == 0 on this path: a lane's 16 columns are all in or all out
-    float bias16[16];
-#pragma unroll
-    for (int e = 0; e < 16; ++e) bias16[e] = 0.f;
-    if (has_bias) ld16(g.bias + n0, bias16);
-    // The output may alias the residual (x += ...), so the compiler keeps every row group's reads behind the previous
-    // group's stores and each group would pay a full memory round trip.  Reads are therefore issued by hand two row
-    // groups ahead of their use (pf ring), the row indices for all four groups first.
     const bool use_aux = act == STAR_ACT_DGELU || act == STAR_ACT_MULAUX || act == STAR_ACT_DRELU;
-    int drow[4], arow[4];
-#pragma unroll
-    for (int b = 0; b < 4; ++b) {
-        const int m = m_blk + wm * 64 + b * 16 + lr;
-        drow[b] = -1;
-        arow[b] = -1;
-        if (m < M) {
-            drow[b] = g.c_rows ? g.c_rows[m] : m;
-            arow[b] = (by_arow && g.a_rows) ? g.a_rows[m] : drow[b];
-        }
+    const int nk = K / NTF_BK;
+
+    // ---- persistent over tiles (grid = resident blocks): the ring of the NEXT tile is filled while this tile's
+    // epilogue runs, and the epilogue's stores drain under the next main loop.  Tiles t, t + grid, ... of one block
+    // stay on its XCD (grid % 8 == 0), and xcd_remap gives each XCD a contiguous range (A panel reuse in its L2).
+    int t = blockIdx.x;
+    int m_blk, n_blk;
+    {
+        const int tile = xcd_remap(t, ntiles);
+        m_blk = (tile / tiles_n) * BM;
+        n_blk = (tile % tiles_n) * BN;
     }
-    float pf[2][16];   // residual rows, or (when there is no residual) the aux rows
-    auto prefetch = [&](int b, float (&dst)[16]) {
-        const int m = m_blk + wm * 64 + b * 16 + lr;
+    dma_setup(m_blk, n_blk);
+    for (int s0 = 0; s0 < PF && s0 < nk; ++s0) issue(s0);
+    bool first = true;
+    while (true) {
+        // ---- epilogue set-up, done BEFORE the main loop so that its global reads (row indices, the first two row
+        // groups of the residual / aux operand) are in flight under the MFMA work.  Lane (lr, lg) owns rows
+        // wm*64 + b*16 + lr (b = 0..3) and the 16 contiguous columns n0 .. n0+15; a 16-lane group covers 16 rows x
+        // 64 (bf16: 32) bytes per store instruction.  The output may alias the residual (x += ...), so the compiler
+        // would keep every row group's reads behind the previous group's stores: reads are issued by hand, two
+        // groups ahead.
+        const int cm_blk = m_blk;
+        const int n0 = n_blk + wn * 64 + lg * 16;
+        const bool col_ok = n0 < N;   // N % 16 == 0 on this path: a lane's 16 columns are all in or all out
+        const int n0c = col_ok ? n0 : 0;
+        int drow[4], arow[4];
 #pragma unroll
-        for (int e = 0; e < 16; ++e) dst[e] = 0.f;
-        if (drow[b] < 0 || (by_arow && arow[b] < 0)) return;
-        if (has_res) {
-            const long long rb = by_arow ? arow[b] : drow[b];
-            ld16(g.res + (size_t)(g.res_mod > 0 ? rb % g.res_mod : rb) * N + n0, dst);
-        } else if (use_aux) {
-            ld16(aux + (size_t)m * N + n0, dst);
+        for (int b = 0; b < 4; ++b) {
+            const int m = cm_blk + wm * 64 + b * 16 + lr;
+            drow[b] = -1;
+            arow[b] = -1;
+            if (m < M) {
+                drow[b] = g.c_rows ? g.c_rows[m] : m;
+                arow[b] = (by_arow && g.a_rows) ? g.a_rows[m] : drow[b];
+            }
         }
-    };
-    if (has_res || use_aux) {
-        prefetch(0, pf[0]);
-        prefetch(1, pf[1]);
-    }
-    // arithmetic and stores, in place in the accumulator registers
+        uint4 pf[2][4];   // raw residual rows (4 x 16 B of float32), or -- without a residual -- aux rows (2 x 16 B of bf16)
+        auto prefetch = [&](int b, uint4 (&dst)[4]) {   // unconditional: rows that will not be stored read a clamped address
+            if (has_res) {
+                const long long rb = max(by_arow ? arow[b] : drow[b], 0);
+                const uint4* src = reinterpret_cast<const uint4*>(g.res + (size_t)(g.res_mod > 0 ? rb % g.res_mod : rb) * N + n0c);
 #pragma unroll
-    for (int bb = 0; bb < 4; ++bb)
+                for (int i = 0; i < 4; ++i) dst[i] = src[i];
+            } else if (use_aux) {
+                const int m = min(cm_blk + wm * 64 + b * 16 + lr, M - 1);
+                const uint4* src = reinterpret_cast<const uint4*>(aux + (size_t)m * N + n0c);
+                dst[0] = src[0];
+                dst[1] = src[1];
+            }
+        };
+        if (has_res || use_aux) {
+            prefetch(0, pf[0]);
+            prefetch(1, pf[1]);
+        }
+
+        f32x4_t acc[4][4];
 #pragma unroll
         for (int a = 0; a < 4; ++a)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc[a][bb][j] += bias16[a * 4 + j];
+            for (int b = 0; b < 4; ++b) acc[a][b] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+        for (int kt = 0; kt < nk; ++kt) {
+            // stages allowed to stay in flight behind stage kt; a later tile's first step also retires the previous
+            // epilogue's stores and this tile's prefetches, whose number is not known: plain vmcnt(0)
+            const int rem = (kt == 0 && !first) ? 0 : min(nk - 1 - kt, PF - 1);
+            if (rem >= 3) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+            else if (rem == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else if (rem == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            if (kt + PF < nk) issue(kt + PF);
+            const unsigned char* st = smem + (kt % NST) * STAGE;
+            short8_t w8[4], x8[4];
 #pragma unroll
-    for (int b = 0; b < 4; ++b) {
-        const int m = m_blk + wm * 64 + b * 16 + lr;
-        const long long d = drow[b];
-        float cur[16];
+            for (int a = 0; a < 4; ++a) w8[a] = *reinterpret_cast<const short8_t*>(st + fw[a]);
 #pragma unroll
-        for (int e = 0; e < 16; ++e) cur[e] = pf[b & 1][e];
-        if (b + 2 < 4 && (has_res || use_aux)) prefetch(b + 2, pf[b & 1]);
-        if (d < 0) continue;
-        float v[16];
-        if (by_arow && arow[b] < 0) {
+            for (int b = 0; b < 4; ++b) x8[b] = *reinterpret_cast<const short8_t*>(st + fx[b]);
 #pragma unroll
-            for (int e = 0; e < 16; ++e) v[e] = 0.f;
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, w8[a]), __builtin_bit_cast(bf16x8_t, x8[b]),
+                                                                        acc[a][b], 0, 0, 0);
+        }
+
+        // ---- hand the ring to the next tile before the epilogue
+        const int tn = t + (int)gridDim.x;
+        const bool more = tn < ntiles;
+        if (more) {
+            __builtin_amdgcn_s_barrier();   // every wave has consumed the last stages
+            asm volatile("" ::: "memory");
+            const int tile = xcd_remap(tn, ntiles);
+            m_blk = (tile / tiles_n) * BM;
+            n_blk = (tile % tiles_n) * BN;
+            dma_setup(m_blk, n_blk);
+            for (int s0 = 0; s0 < PF && s0 < nk; ++s0) issue(s0);
+        }
+
+        // ---- epilogue straight from the accumulators (its stores drain under the next tile's main loop)
+        if (col_ok) {
+        float bias16[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) bias16[e] = 0.f;
+        if (has_bias) ld16(g.bias + n0, bias16);
+        // arithmetic and stores, in place in the accumulator registers
+#pragma unroll
+        for (int bb = 0; bb < 4; ++bb)
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[a][bb][j] += bias16[a * 4 + j];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int m = cm_blk + wm * 64 + b * 16 + lr;
+            const long long d = drow[b];
+            float cur[16];
+            if (has_res) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    cur[4 * i] = __uint_as_float(pf[b & 1][i].x); cur[4 * i + 1] = __uint_as_float(pf[b & 1][i].y);
+                    cur[4 * i + 2] = __uint_as_float(pf[b & 1][i].z); cur[4 * i + 3] = __uint_as_float(pf[b & 1][i].w);
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const unsigned w[4] = {pf[b & 1][i].x, pf[b & 1][i].y, pf[b & 1][i].z, pf[b & 1][i].w};
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        cur[8 * i + 2 * k] = __uint_as_float(w[k] << 16);
+                        cur[8 * i + 2 * k + 1] = __uint_as_float(w[k] & 0xffff0000u);
+                    }
+                }
+            }
+            if (b + 2 < 4 && (has_res || use_aux)) prefetch(b + 2, pf[b & 1]);
+            if (d < 0) continue;
+            float v[16];
+            if (by_arow && arow[b] < 0) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) v[e] = 0.f;
+                if (out_lp) st16(out_lp + (size_t)d * N + n0, v);
+                if (g.out_f32) st16(g.out_f32 + (size_t)d * N + n0, v);
+                continue;
+            }
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[a * 4 + j] = acc[a][b][j];
+            if (has_pre && !pre_grad) st16(pre + (size_t)d * N + n0, v);
+            if (act == STAR_ACT_GELU) {
+                if (has_pre && pre_grad) {
+                    float dv[16];
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) gelu_both(v[e], v[e], dv[e]);
+                    st16(pre + (size_t)d * N + n0, dv);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) v[e] = gelu_f(v[e]);
+                }
+            } else if (act == STAR_ACT_RELU) {
+                if (has_pre && pre_grad) {
+                    float dv[16];
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) dv[e] = v[e] > 0.f ? 1.f : 0.f;
+                    st16(pre + (size_t)d * N + n0, dv);
+                }
+#pragma unroll
+                for (int e = 0; e < 16; ++e) v[e] = fmaxf(v[e], 0.f);
+            } else if (use_aux) {
+                if (has_res) {   // both a residual and an activation gradient: the aux row was not prefetched
+                    float t[16];
+                    ld16(aux + (size_t)m * N + n0, t);
+#pragma unroll
+                    for (int e = 0; e < 16; ++e)
+                        v[e] = act == STAR_ACT_DGELU ? v[e] * dgelu_f(t[e]) : (act == STAR_ACT_MULAUX ? v[e] * t[e] : (t[e] > 0.f ? v[e] : 0.f));
+                } else if (act == STAR_ACT_DGELU) {
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) v[e] *= dgelu_f(cur[e]);
+                } else if (act == STAR_ACT_MULAUX) {
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) v[e] *= cur[e];
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) v[e] = cur[e] > 0.f ? v[e] : 0.f;
+                }
+            }
+            if (has_res) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) v[e] += cur[e];
+            }
+            if (has_res2) {
+                const int rr = (m / g.res2_div) % g.res2_mod;
+                float t2[16];
+                ld16(g.res2 + (size_t)rr * N + n0, t2);
+#pragma unroll
+                for (int e = 0; e < 16; ++e) v[e] += t2[e];
+            }
             if (out_lp) st16(out_lp + (size_t)d * N + n0, v);
             if (g.out_f32) st16(g.out_f32 + (size_t)d * N + n0, v);
-            continue;
         }
-#pragma unroll
-        for (int a = 0; a < 4; ++a)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) v[a * 4 + j] = acc[a][b][j];
-        if (has_pre && !pre_grad) st16(pre + (size_t)d * N + n0, v);
-        if (act == STAR_ACT_GELU) {
-            if (has_pre && pre_grad) {
-                float dv[16];
-#pragma unroll
-                for (int e = 0; e < 16; ++e) gelu_both(v[e], v[e], dv[e]);
-                st16(pre + (size_t)d * N + n0, dv);
-            } else {
-#pragma unroll
-                for (int e = 0; e < 16; ++e) v[e] = gelu_f(v[e]);
-            }
-        } else if (act == STAR_ACT_RELU) {
-            if (has_pre && pre_grad) {
-                float dv[16];
-#pragma unroll
-                for (int e = 0; e < 16; ++e) dv[e] = v[e] > 0.f ? 1.f : 0.f;
-                st16(pre + (size_t)d * N + n0, dv);
-            }
-#pragma unroll
-            for (int e = 0; e < 16; ++e) v[e] = fmaxf(v[e], 0.f);
-        } else if (use_aux) {
-            if (has_res) {   // both a residual and an activation gradient: the aux row was not prefetched
-                float t[16];
-                ld16(aux + (size_t)m * N + n0, t);
-#pragma unroll
-                for (int e = 0; e < 16; ++e)
-                    v[e] = act == STAR_ACT_DGELU ? v[e] * dgelu_f(t[e]) : (act == STAR_ACT_MULAUX ? v[e] * t[e] : (t[e] > 0.f ? v[e] : 0.f));
-            } else if (act == STAR_ACT_DGELU) {
-#pragma unroll
-                for (int e = 0; e < 16; ++e) v[e] *= dgelu_f(cur[e]);
-            } else if (act == STAR_ACT_MULAUX) {
-#pragma unroll
-                for (int e = 0; e < 16; ++e) v[e] *= cur[e];
-            } else {
-#pragma unroll
-                for (int e = 0; e < 16; ++e) v[e] = cur[e] > 0.f ? v[e] : 0.f;
-            }
         }
-        if (has_res) {
-#pragma unroll
-            for (int e = 0; e < 16; ++e) v[e] += cur[e];
-        }
-        if (has_res2) {
-            const int rr = (m / g.res2_div) % g.res2_mod;
-            float t2[16];
-            ld16(g.res2 + (size_t)rr * N + n0, t2);
-#pragma unroll
-            for (int e = 0; e < 16; ++e) v[e] += t2[e];
-        }
-        if (out_lp) st16(out_lp + (size_t)d * N + n0, v);
-        if (g.out_f32) st16(g.out_f32 + (size_t)d * N + n0, v);
+        if (!more) break;
+        t = tn;
+        first = false;
     }
 }
 
@@ -520,6 +569,9 @@ static void launch_nt_fast_epi(const StarGemm* g, hipStream_t s) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_fast_kernel<NST, EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_done = true;
     }
+    // The kernel can walk several tiles per block (grid < tiles), prefilling the next tile's ring under the epilogue.
+    // Measured on MI355X this is no faster than one tile per block (time = main loops + epilogue bytes / ~5.5 TB/s
+    // either way), so every tile gets its own block and the hardware dispatcher balances the tail.
     hipLaunchKernelGGL((gemm_nt_fast_kernel<NST, EPI>), dim3(tiles), dim3(GT), lds, s, *g);
 }
 template <int NST>

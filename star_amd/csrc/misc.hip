@@ -12,6 +12,18 @@ int star_set_error(int code, const char* fmt, ...) {
     return code;
 }
 
+int star_num_cus() {
+    static int cached[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    if (cached[dev] == 0) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        cached[dev] = n;
+    }
+    return cached[dev];
+}
+
 extern "C" const char* star_last_error(void) { return g_err; }
 extern "C" int star_version(void) { return 100; }
 
