@@ -44,7 +44,11 @@ const char* star_last_error(void);
  * Bit-exact with the reference CPU path (half-to-even rounding, zero padding, k-ordered fma chain). */
 int star_warp_fuse(const uint8_t* pred, const float* ego, int64_t ego_sn, int64_t ego_sc, int64_t ego_sh,
                    int64_t ego_sw, const float* theta, const void* num_agent, int num_agent_is64,
-                   float* out, int B, int A, int C, int H, int W, void* stream);
+                   float* out, void* bits_ws, int B, int A, int C, int H, int W, void* stream);
+/* Optional fast path for {0,1} maps (the arg-max decisions) with C <= 16: pass a workspace of star_warp_fuse_ws()
+ * bytes as bits_ws; the channels of a pixel are packed into one uint16 and gathered together.  Same result, bit for
+ * bit, as bits_ws = NULL (which accepts any uint8 values). */
+int64_t star_warp_fuse_ws(int B, int A, int H, int W);
 
 /* ---- K5: mask index build ------------------------------------------------------------------------
  * Replaces ids_shuffle = argsort(noise); ids_restore = argsort(ids_shuffle)

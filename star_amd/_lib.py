@@ -35,7 +35,8 @@ _P, _I, _L, _F = C.c_void_p, C.c_int, C.c_int64, C.c_float
 _SIGS = {
     "star_version": (C.c_int, []),
     "star_last_error": (C.c_char_p, []),
-    "star_warp_fuse": (C.c_int, [_P, _P, _L, _L, _L, _L, _P, _P, _I, _P, _I, _I, _I, _I, _I, _P]),
+    "star_warp_fuse": (C.c_int, [_P, _P, _L, _L, _L, _L, _P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "star_warp_fuse_ws": (C.c_int64, [_I, _I, _I, _I]),
     "star_mask_sort": (C.c_int, [_P, _P, _P, _I, _I, _P]),
     "star_build_rowmaps": (C.c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "star_layernorm_fwd": (C.c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _F, _I, _P]),

@@ -122,14 +122,113 @@ __global__ __launch_bounds__(WF_THREADS) void warp_fuse_kernel(
     }
 }
 
+// ---- binary maps: the C <= 16 occupancy decisions of a pixel packed into one uint16 (bit c = channel c).  The
+// gather then is ONE 2-byte load per (pixel, neighbour) instead of C single-byte loads from C planes, and the union
+// is an OR.  Same index arithmetic as above, so the result is bit-identical for {0,1} maps.
+__global__ __launch_bounds__(WF_THREADS) void wf_pack_bits_kernel(const uint8_t* __restrict__ pred, uint16_t* __restrict__ bits,
+                                                                  int C, int64_t HW, int64_t total4) {
+    const int64_t q = (int64_t)blockIdx.x * WF_THREADS + threadIdx.x;   // 4 pixels
+    if (q >= total4) return;
+    const int64_t pix = q << 2, f = pix / HW, r = pix - f * HW;
+    unsigned m[4] = {0, 0, 0, 0};
+    for (int c = 0; c < C; ++c) {
+        const uchar4 v = *reinterpret_cast<const uchar4*>(pred + (f * C + c) * HW + r);
+        m[0] |= (unsigned)(v.x != 0) << c; m[1] |= (unsigned)(v.y != 0) << c;
+        m[2] |= (unsigned)(v.z != 0) << c; m[3] |= (unsigned)(v.w != 0) << c;
+    }
+    *reinterpret_cast<uint2*>(bits + pix) = make_uint2(m[0] | (m[1] << 16), m[2] | (m[3] << 16));
+}
+
+__global__ __launch_bounds__(WF_THREADS) void warp_fuse_bits_kernel(
+    const uint16_t* __restrict__ bits, const float* __restrict__ ego, int64_t esn, int64_t esc, int64_t esh,
+    int64_t esw, const float* __restrict__ theta, const void* __restrict__ num_agent, int na64,
+    float* __restrict__ out, int B, int A, int C, int H, int W) {
+    extern __shared__ float s_base[];  // [W] x-grid, then [H] y-grid
+    float* bx = s_base;
+    float* by = s_base + W;
+    for (int t = threadIdx.x; t < W; t += WF_THREADS) bx[t] = wf_base(t, W);
+    for (int t = threadIdx.x; t < H; t += WF_THREADS) by[t] = wf_base(t, H);
+    __syncthreads();
+
+    const int i = blockIdx.y, b = blockIdx.z;
+    const int wq = W >> 2;
+    const int q = blockIdx.x * WF_THREADS + threadIdx.x;
+    if (q >= H * wq) return;
+    const int y = q / wq, x0 = (q - y * wq) << 2;
+
+    long long nraw = na64 ? ((const long long*)num_agent)[(size_t)b * A] : (long long)((const int*)num_agent)[(size_t)b * A];
+    const int n = nraw < 0 ? 0 : (nraw > A ? A : (int)nraw);
+    const size_t HW = (size_t)H * W;
+    const size_t own = (size_t)(i * B + b) * C * HW;
+    const float fW = (float)W, fH = (float)H;
+    const float byy = by[y];
+
+    unsigned nb[4] = {0, 0, 0, 0};   // union of the warped neighbours, per pixel
+    if (i < n) {
+        for (int j = 0; j < n; ++j) {
+            if (j == i) continue;
+            const float* th = theta + ((size_t)(b * A + i) * A + j) * 8;
+            const float r00 = th[0], r01 = th[1], r10 = th[2], r11 = th[3], tx = th[4], ty = th[5];
+            const float py = wf_pix(__fadd_rn(byy, ty), fH);
+            const uint16_t* src = bits + (size_t)(j * B + b) * HW;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float px = wf_pix(__fadd_rn(bx[x0 + k], tx), fW);
+                if (px >= 0.0f && px < fW && py >= 0.0f && py < fH) {
+                    const float gx0 = bx[(int)px], gy0 = by[(int)py];
+                    const float gx = __fmaf_rn(gy0, r01, __fmul_rn(gx0, r00));
+                    const float gy = __fmaf_rn(gy0, r11, __fmul_rn(gx0, r10));
+                    const float sx = wf_pix(gx, fW), sy = wf_pix(gy, fH);
+                    if (sx >= 0.0f && sx < fW && sy >= 0.0f && sy < fH) nb[k] |= src[(int)sy * W + (int)sx];
+                }
+            }
+        }
+    }
+    const bool from_ego = ego != nullptr && i < n;
+    unsigned ob[4] = {0, 0, 0, 0};
+    if (!from_ego) {
+        const uint2 w = *reinterpret_cast<const uint2*>(bits + (size_t)(i * B + b) * HW + (size_t)y * W + x0);
+        ob[0] = w.x & 0xffff; ob[1] = w.x >> 16; ob[2] = w.y & 0xffff; ob[3] = w.y >> 16;
+    }
+    for (int c = 0; c < C; ++c) {
+        float4 o;
+        if (from_ego) {   // acc = ego + neighbours, then fused[fused > 0] = 1
+            const float* e = ego + (int64_t)(i * B + b) * esn + (int64_t)c * esc + (int64_t)y * esh + (int64_t)x0 * esw;
+            float a[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                a[k] = e[(int64_t)k * esw] + (float)((nb[k] >> c) & 1u);
+                a[k] = a[k] > 0.0f ? 1.0f : a[k];
+            }
+            o = make_float4(a[0], a[1], a[2], a[3]);
+        } else {
+            o = make_float4((float)(((ob[0] | nb[0]) >> c) & 1u), (float)(((ob[1] | nb[1]) >> c) & 1u),
+                            (float)(((ob[2] | nb[2]) >> c) & 1u), (float)(((ob[3] | nb[3]) >> c) & 1u));
+        }
+        *reinterpret_cast<float4*>(out + own + (size_t)c * HW + (size_t)y * W + x0) = o;
+    }
+}
+
+extern "C" int64_t star_warp_fuse_ws(int B, int A, int H, int W) { return (int64_t)B * A * H * W * (int64_t)sizeof(uint16_t); }
+
 extern "C" int star_warp_fuse(const uint8_t* pred, const float* ego, int64_t ego_sn, int64_t ego_sc,
                               int64_t ego_sh, int64_t ego_sw, const float* theta, const void* num_agent,
-                              int num_agent_is64, float* out, int B, int A, int C, int H, int W, void* stream) {
+                              int num_agent_is64, float* out, void* bits_ws, int B, int A, int C, int H, int W, void* stream) {
     STAR_CHECK(pred && theta && num_agent && out, "star_warp_fuse: null pointer");
     STAR_CHECK(B > 0 && A > 0 && C > 0 && H > 1 && W > 1, "star_warp_fuse: bad shape B=%d A=%d C=%d H=%d W=%d", B, A, C, H, W);
     STAR_CHECK(W % 4 == 0 && H <= 4096 && W <= 4096, "star_warp_fuse: W must be a multiple of 4 and H,W <= 4096");
     STAR_CHECK(A <= 65535 && B <= 65535, "star_warp_fuse: A,B too large for the grid");
     dim3 grid(cdiv((int64_t)H * (W / 4), WF_THREADS), A, B);
+    if (bits_ws && C <= 16) {   // binary maps: pack once, gather 2 bytes per pixel and neighbour
+        STAR_CHECK((reinterpret_cast<uintptr_t>(bits_ws) & 7) == 0, "star_warp_fuse: bits_ws must be 8-byte aligned");
+        const int64_t total4 = (int64_t)A * B * H * W / 4;
+        hipLaunchKernelGGL(wf_pack_bits_kernel, dim3(cdiv(total4, WF_THREADS)), dim3(WF_THREADS), 0, (hipStream_t)stream, pred,
+                           (uint16_t*)bits_ws, C, (int64_t)H * W, total4);
+        hipLaunchKernelGGL(warp_fuse_bits_kernel, grid, dim3(WF_THREADS), (size_t)(H + W) * sizeof(float), (hipStream_t)stream,
+                           (const uint16_t*)bits_ws, ego, ego_sn, ego_sc, ego_sh, ego_sw, theta, num_agent, num_agent_is64, out, B, A, C, H, W);
+        STAR_LAUNCH_CHECK("star_warp_fuse(bits)");
+        return 0;
+    }
     hipLaunchKernelGGL(warp_fuse_kernel, grid, dim3(WF_THREADS), (size_t)(H + W) * sizeof(float), (hipStream_t)stream,
                        pred, ego, ego_sn, ego_sc, ego_sh, ego_sw, theta, num_agent, num_agent_is64, out, B, A, C, H, W);
     STAR_LAUNCH_CHECK("star_warp_fuse");

@@ -287,7 +287,7 @@ def forward(cfg, P, W, dt, imgs1, imgs_next, trans_matrices, num_agent, batch, m
     na = num_agent if num_agent.is_cuda else num_agent.to(dev)
     if na.dtype not in (torch.int32, torch.int64):
         na = na.long()
-    result = ops.warp_fuse(ce["ind8"], theta, na.contiguous(), batch, ego=imgs1 if infer else None)
+    result = ops.warp_fuse(ce["ind8"], theta, na.contiguous(), batch, ego=imgs1 if infer else None, binary=True)
     out = dict(loss=ce["loss"], result=result, latent=latent.reshape(n_frames, keep, cfg.inter), ind=ce["ind64"])
     ctx = None
     if train:

@@ -74,9 +74,10 @@ def warp_thetas(trans_matrices):
     return out
 
 
-def warp_fuse(pred_u8, theta, num_agent, batch, ego=None):
+def warp_fuse(pred_u8, theta, num_agent, batch, ego=None, binary=False):
     """K10.  pred_u8 uint8 [A*B,C,H,W]; theta float32 [B,A,A,8] on the device; num_agent int [B,A] on
-    the device; ego optional float32 [A*B,C,H,W] with any strides.  -> float32 [A*B,C,H,W]."""
+    the device; ego optional float32 [A*B,C,H,W] with any strides.  -> float32 [A*B,C,H,W].
+    binary=True promises {0,1} maps and takes the bit-packed fast path (identical result)."""
     _cuda(pred_u8, theta, num_agent, ego)
     ab, c, h, w = pred_u8.shape
     assert ab % batch == 0, (pred_u8.shape, batch)
@@ -89,9 +90,12 @@ def warp_fuse(pred_u8, theta, num_agent, batch, ego=None):
     if ego is not None:
         assert ego.dtype == torch.float32 and tuple(ego.shape) == (ab, c, h, w)
         es = ego.stride()
+    ws = None
+    if binary and c <= 16:
+        ws = torch.empty(L.lib().star_warp_fuse_ws(batch, a, h, w) // 8 + 1, dtype=torch.int64, device=pred_u8.device)
     with _timed("warp_fuse", 0.0, float(ab) * (a + 1) * c * h * w * 4):   # (A+1) x 3.41 MB per ego frame
         L.check(L.lib().star_warp_fuse(p(pred_u8), p(ego), es[0], es[1], es[2], es[3], p(theta), p(num_agent),
-                                       int(num_agent.dtype == torch.int64), p(out), batch, a, c, h, w, L.stream()))
+                                       int(num_agent.dtype == torch.int64), p(out), p(ws), batch, a, c, h, w, L.stream()))
     return out
 
 

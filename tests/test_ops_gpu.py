@@ -37,13 +37,15 @@ def test_warp_fuse_golden_full_resolution_bit_exact():
     nad = torch.from_numpy(na).to(DEV)
     for tr, key in ((trans, "late_bits"), (trans.astype(np.float32), "late32_bits")):
         theta = ops.warp_thetas(torch.from_numpy(tr)).to(DEV)
-        out = ops.warp_fuse(pred, theta, nad, B)
-        assert np.array_equal(out.cpu().numpy(), unpack(z[key], z["shape"])), key
+        for binary in (False, True):   # generic uint8 path and the bit-packed path for {0,1} maps
+            out = ops.warp_fuse(pred, theta, nad, B, binary=binary)
+            assert np.array_equal(out.cpu().numpy(), unpack(z[key], z["shape"])), (key, binary)
     theta = ops.warp_thetas(torch.from_numpy(trans)).to(DEV)
     # ego = ground truth input, handed over as NHWC memory viewed NCHW (what CoModule does)
     ego = torch.from_numpy(gt).to(DEV).permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)
-    out = ops.warp_fuse(pred, theta, nad.int(), B, ego=ego)
-    assert np.array_equal(out.cpu().numpy(), unpack(z["ego_bits"], z["shape"]))
+    for binary in (False, True):
+        out = ops.warp_fuse(pred, theta, nad.int(), B, ego=ego, binary=binary)
+        assert np.array_equal(out.cpu().numpy(), unpack(z["ego_bits"], z["shape"])), binary
 
 
 def test_warp_fuse_random_poses_vs_oracle():
@@ -58,8 +60,10 @@ def test_warp_fuse_random_poses_vs_oracle():
                 trans[b, i, j] = [[math.cos(yaw), -math.sin(yaw), 0, tx], [math.sin(yaw), math.cos(yaw), 0, ty], [0, 0, 1, 0], [0, 0, 0, 1]]
     na = np.array([[4] * A, [2] * A])
     want = O.late_fusion(ind.astype(np.float32), trans, na, B)
-    out = ops.warp_fuse(torch.from_numpy(ind).to(DEV), ops.warp_thetas(torch.from_numpy(trans)).to(DEV), torch.from_numpy(na).to(DEV), B)
-    assert np.array_equal(out.cpu().numpy(), want)
+    for binary in (False, True):
+        out = ops.warp_fuse(torch.from_numpy(ind).to(DEV), ops.warp_thetas(torch.from_numpy(trans)).to(DEV), torch.from_numpy(na).to(DEV), B,
+                            binary=binary)
+        assert np.array_equal(out.cpu().numpy(), want), binary
 
 
 @pytest.mark.parametrize("R,L", [(5, 16), (7, 1024), (3, 342), (2, 4096), (40, 1024)])
