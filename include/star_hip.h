@@ -190,6 +190,16 @@ int star_cast_transpose(const float* src, void* dst, int R, int C, int dt, void*
  * cast float32 -> dt for many tensors in one launch is done by star_cast; star_colsum gives bias grads. */
 int star_cast(const float* src, void* dst, int64_t n, int dt, void* stream);
 int star_cast_back(const void* src, float* dst, int64_t n, int dt, void* stream);
+/* The per-step refresh of every low-precision weight copy in one launch.  jobs_dev: device array, sorted by
+ * tile_start (running count of 64x64 tiles, first = 0); total_tiles = sum over jobs of ceil(rows/64)*ceil(cols/64). */
+typedef struct StarCastJob {
+    const float* src;   /* float32 [rows, cols] */
+    void* dst;          /* dt [rows, cols], or [cols, rows] when transpose != 0 */
+    int32_t rows, cols;
+    int32_t transpose;
+    int32_t tile_start;
+} StarCastJob;
+int star_cast_batch(const StarCastJob* jobs_dev, int njobs, int total_tiles, int dt, void* stream);
 /* AdamW (decoupled weight decay) over one flat float32 buffer, torch.optim.AdamW semantics
  * (train_completion.py:125): p -= lr*wd*p; m,v updates; p -= lr/bc1 * m / (sqrt(v)/sqrt(bc2) + eps).
  * wd_mask uint8 per element (1 = decay) or NULL; gscale optional device scalar multiplied into g. */

@@ -60,6 +60,7 @@ _SIGS = {
     "star_cast_transpose": (C.c_int, [_P, _P, _I, _I, _I, _P]),
     "star_cast": (C.c_int, [_P, _P, _L, _I, _P]),
     "star_cast_back": (C.c_int, [_P, _P, _L, _I, _P]),
+    "star_cast_batch": (C.c_int, [_P, _I, _I, _I, _P]),
     "star_adamw": (C.c_int, [_P, _P, _P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _I, _P]),
     "star_sumsq": (C.c_int, [_P, _L, _P, _P, _P]),
     "star_iou_confusion": (C.c_int, [_P, _P, _P, _I, _I, _I, _I, _P]),

@@ -69,6 +69,48 @@ extern "C" int star_cast(const float* src, void* dst, int64_t n, int dt, void* s
     return 0;
 }
 
+// All weight copies of a training step in ONE launch: job j converts float32 [rows, cols] to dt, as is or transposed
+// ([cols, rows]), in 64 x 64 tiles; tile_start is the running tile count (jobs sorted, last entry = total).
+template <typename T>
+__global__ __launch_bounds__(256) void cast_batch_kernel(const StarCastJob* __restrict__ jobs, int njobs) {
+    __shared__ float tile[64][65];
+    int j = 0;
+    while (j + 1 < njobs && (int)blockIdx.x >= jobs[j + 1].tile_start) ++j;
+    const StarCastJob job = jobs[j];
+    const int tc = (job.cols + 63) >> 6;
+    const int t = blockIdx.x - job.tile_start, r0 = (t / tc) << 6, c0 = (t % tc) << 6;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    T* dst = (T*)job.dst;
+    if (!job.transpose) {
+#pragma unroll 4
+        for (int i = ty; i < 64; i += 4) {
+            const int r = r0 + i, c = c0 + tx;
+            if (r < job.rows && c < job.cols) Act<T>::st(dst + (size_t)r * job.cols + c, job.src[(size_t)r * job.cols + c]);
+        }
+        return;
+    }
+#pragma unroll 4
+    for (int i = ty; i < 64; i += 4) {
+        const int r = r0 + i, c = c0 + tx;
+        tile[i][tx] = (r < job.rows && c < job.cols) ? job.src[(size_t)r * job.cols + c] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int i = ty; i < 64; i += 4) {
+        const int c = c0 + i, r = r0 + tx;
+        if (r < job.rows && c < job.cols) Act<T>::st(dst + (size_t)c * job.rows + r, tile[tx][i]);
+    }
+}
+
+extern "C" int star_cast_batch(const StarCastJob* jobs_dev, int njobs, int total_tiles, int dt, void* stream) {
+    STAR_CHECK(jobs_dev && njobs > 0 && total_tiles > 0, "star_cast_batch: bad arguments");
+    STAR_CHECK(dt == STAR_BF16 || dt == STAR_F32, "star_cast_batch: unknown dtype %d", dt);
+    if (dt == STAR_BF16) hipLaunchKernelGGL(cast_batch_kernel<bf16_t>, dim3(total_tiles), dim3(256), 0, (hipStream_t)stream, jobs_dev, njobs);
+    else hipLaunchKernelGGL(cast_batch_kernel<float>, dim3(total_tiles), dim3(256), 0, (hipStream_t)stream, jobs_dev, njobs);
+    STAR_LAUNCH_CHECK("star_cast_batch");
+    return 0;
+}
+
 extern "C" int star_cast_back(const void* src, float* dst, int64_t n, int dt, void* stream) {
     STAR_CHECK(src && dst && n >= 0, "star_cast_back: bad arguments");
     if (n == 0) return 0;

@@ -60,6 +60,30 @@ class Weights:
     def __init__(self):
         self.cache = {}
         self.epoch = 0
+        self.plain = {}      # key -> [param, dst, transposed, versions]: plain casts, refreshed together in one launch
+        self.table = None    # (device job table, njobs, tiles, dt, signature)
+
+    def linear(self, key, w, dt, transposed):
+        """The dt copy of weight `w` ([N,K], or [K,N] when transposed).  A stale copy triggers ONE batched launch that
+        refreshes every registered copy (they all go stale together: one optimizer step)."""
+        versions = (w._version, self.epoch)
+        ent = self.plain.get(key)
+        if ent is not None and ent[0].data_ptr() == w.data_ptr() and ent[3] == versions:
+            return ent[1]
+        if ent is None or ent[0].data_ptr() != w.data_ptr() or ent[1].device != w.device:
+            dst = ops.cast_transpose(w.detach(), dt) if transposed else ops.cast(w.detach(), dt)
+            self.plain[key] = [w, dst, transposed, versions]
+            self.table = None
+            return dst
+        same_dt = [e for k, e in self.plain.items() if k[1] == dt]
+        sig = tuple((e[0].data_ptr(), e[1].data_ptr()) for e in same_dt)
+        if self.table is None or self.table[3] != dt or self.table[4] != sig:
+            tab, n, tiles = ops.cast_batch_table([(e[0].detach(), e[1], e[2]) for e in same_dt], w.device)
+            self.table = (tab, n, tiles, dt, sig)
+        ops.cast_batch(self.table[0], self.table[1], self.table[2], dt)
+        for e in same_dt:
+            e[3] = (e[0]._version, self.epoch)
+        return ent[1]
 
     def get(self, key, versions, build):
         versions = (versions, self.epoch)
@@ -73,10 +97,7 @@ class Weights:
 
 def _lin(P, W, name, dt, transposed=False):
     w = P[name + ".weight"]
-    key = (name, dt, transposed)
-    if transposed:
-        return W.get(key, w._version, lambda: ops.cast_transpose(w.detach(), dt))
-    return W.get(key, w._version, lambda: ops.cast(w.detach(), dt))
+    return W.linear((name, dt, transposed), w, dt, transposed)
 
 
 def _heads(P, W, cfg, dt, transposed=False):

@@ -325,6 +325,21 @@ def cast(src, dt):
     return dst
 
 
+def cast_batch_table(jobs, device):
+    """jobs: list of (src float32 [R,C], dst, transposed).  -> (int64 device table, njobs, total_tiles) for cast_batch."""
+    rows, start = [], 0
+    for src, dst, tr in jobs:
+        r, c = src.shape
+        assert src.dtype == torch.float32 and src.is_contiguous() and dst.is_contiguous() and dst.numel() == r * c
+        rows.append([src.data_ptr(), dst.data_ptr(), r | (c << 32), int(bool(tr)) | (start << 32)])   # StarCastJob, little endian
+        start += ((r + 63) // 64) * ((c + 63) // 64)
+    return torch.tensor(rows, dtype=torch.int64).to(device), len(jobs), start
+
+
+def cast_batch(table, njobs, total_tiles, dt):
+    L.check(L.lib().star_cast_batch(p(table), njobs, total_tiles, dt, L.stream()))
+
+
 def cast_back(src):
     dst = torch.empty(src.shape, dtype=torch.float32, device=src.device)
     L.check(L.lib().star_cast_back(p(src), p(dst), src.numel(), L.dt_of(src), L.stream()))

@@ -393,3 +393,18 @@ def test_attention_one_hot_rows_catch_layout_errors():
     out, _ = ops.attn_fwd(q16, NB, L, H, hd)
     want = qkv[tgt, 2, 0, :]
     torch.testing.assert_close(out.float(), want, rtol=0, atol=1e-2)
+
+
+def test_cast_batch_matches_single_casts():
+    g = torch.Generator().manual_seed(11)
+    for dt, td in ((BF16, torch.bfloat16), (F32, torch.float32)):
+        jobs = []
+        for (r, c, tr) in [(384, 384, False), (1152, 384, True), (70, 130, True), (33, 64, False), (1, 8, True)]:
+            src = torch.randn(r, c, generator=g).to(DEV)
+            dst = torch.empty((c, r) if tr else (r, c), dtype=td, device=DEV)
+            jobs.append((src, dst, tr))
+        tab, n, tiles = ops.cast_batch_table(jobs, DEV)
+        ops.cast_batch(tab, n, tiles, dt)
+        for src, dst, tr in jobs:
+            want = ops.cast_transpose(src, dt) if tr else ops.cast(src, dt)
+            assert torch.equal(dst, want), (src.shape, tr)
