@@ -190,18 +190,6 @@ __device__ __forceinline__ float xor32_max(float x) {
     return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
 }
 
-// Transposed LDS reads as inline asm: the compiler treats the builtin as aliasing every LDS-DMA in flight and
-// puts a full vmcnt(0) in front of it, which would serialise the ring.  The asm form is invisible to its wait
-// insertion, so the matching lgkmcnt wait is explicit (tr_wait) and carries the registers as operands to pin
-// the order.
-__device__ __forceinline__ unsigned lds_u32(const unsigned char* p) {
-    return (unsigned)(uintptr_t)(__attribute__((address_space(3))) const unsigned char*)p;
-}
-template <int OFF> __device__ __forceinline__ short4_t tr16(unsigned addr) {
-    short4_t r;
-    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(OFF));
-    return r;
-}
 // the four 16-row k-slices of a 64-row image (rows +0, +16, +32, +48), low and high 8-row halves
 template <int RB> __device__ __forceinline__ void tr_issue(unsigned a_lo, unsigned a_hi, short4_t (&lo)[4], short4_t (&hi)[4]) {
     lo[0] = tr16<0>(a_lo);        hi[0] = tr16<0>(a_hi);

@@ -22,6 +22,7 @@ int star_num_cus();   // compute units of the current device (cached)
     } while (0)
 
 typedef unsigned short bf16_t;  // raw bf16 bits
+typedef __attribute__((ext_vector_type(4))) short star_short4_t;
 
 __device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((unsigned)v) << 16); }
 
@@ -104,6 +105,18 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
+// Transposed LDS reads as inline asm: the compiler treats the builtin as aliasing every LDS-DMA in flight and
+// puts a full vmcnt(0) in front of it, which would serialise the ring.  The asm form is invisible to its wait
+// insertion, so the matching lgkmcnt wait is explicit (tr_wait) and carries the registers as operands to pin
+// the order.
+__device__ __forceinline__ unsigned lds_u32(const unsigned char* p) {
+    return (unsigned)(uintptr_t)(__attribute__((address_space(3))) const unsigned char*)p;
+}
+template <int OFF> __device__ __forceinline__ star_short4_t tr16(unsigned addr) {
+    star_short4_t r;
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(OFF));
+    return r;
+}
 // Workgroups are dealt to the 8 XCDs round-robin (block b runs on XCD b % 8, each with its own L2).  This maps
 // the launch index to a work index such that every XCD walks a CONTIGUOUS range of work items (bijective).
 __device__ __forceinline__ int xcd_remap(int bid, int nblk) {

@@ -833,6 +833,7 @@ __global__ __launch_bounds__(GT) void gemm_tn_fast_kernel(const bf16_t* __restri
         axh[a] = TB + tn_off(r0 + 4, wk * 4 + a) + lp * 8;
         ayh[a] = tn_off(r0 + 4, wn * 4 + a) + lp * 8;
     }
+    const unsigned lds_base = lds_u32(smem);
     const int nsteps = (m_end - m_begin + 31) / 32;
     for (int s0 = 0; s0 < PF && s0 < nsteps; ++s0) issue(s0);
     for (int st = 0; st < nsteps; ++st) {
@@ -844,17 +845,27 @@ __global__ __launch_bounds__(GT) void gemm_tn_fast_kernel(const bf16_t* __restri
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         if (st + PF < nsteps) issue(st + PF);
-        const unsigned char* sb = smem + (st % NST) * STAGE;
-        short8_t fx[4], fy[4];
+        // transposed reads as inline asm (common.h): the builtin would make the compiler drain the DMA ring (vmcnt(0))
+        const unsigned sb = lds_base + (st % NST) * STAGE;
+        short4_t xl[4], xh[4], yl[4], yh[4];
 #pragma unroll
         for (int a = 0; a < 4; ++a) {
-            const short4_t lo = ds_read_tr16(sb + ax[a]), hi = ds_read_tr16(sb + axh[a]);
-            fx[a] = (short8_t){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            xl[a] = tr16<0>(sb + ax[a]);
+            xh[a] = tr16<0>(sb + axh[a]);
         }
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
-            const short4_t lo = ds_read_tr16(sb + ay[b]), hi = ds_read_tr16(sb + ayh[b]);
-            fy[b] = (short8_t){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            yl[b] = tr16<0>(sb + ay[b]);
+            yh[b] = tr16<0>(sb + ayh[b]);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+v"(xl[0]), "+v"(xl[1]), "+v"(xl[2]), "+v"(xl[3]), "+v"(xh[0]), "+v"(xh[1]), "+v"(xh[2]), "+v"(xh[3]));
+        asm volatile("" : "+v"(yl[0]), "+v"(yl[1]), "+v"(yl[2]), "+v"(yl[3]), "+v"(yh[0]), "+v"(yh[1]), "+v"(yh[2]), "+v"(yh[3]));
+        short8_t fx[4], fy[4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            fx[a] = (short8_t){xl[a][0], xl[a][1], xl[a][2], xl[a][3], xh[a][0], xh[a][1], xh[a][2], xh[a][3]};
+            fy[a] = (short8_t){yl[a][0], yl[a][1], yl[a][2], yl[a][3], yh[a][0], yh[a][1], yh[a][2], yh[a][3]};
         }
 #pragma unroll
         for (int a = 0; a < 4; ++a)
@@ -988,7 +999,9 @@ static void wgrad_plan(int M, int N, int K, int dt, int* S, int* m_per, int* SC,
     const int tile = dt == STAR_BF16 ? WG_TILE : 64;
     const int step = dt == STAR_BF16 ? WG_BKM : 16;
     const int tiles = cdiv(N, tile) * cdiv(K, tile);
-    int s = cdiv(768, tiles);                  // aim for ~3 blocks per CU: the slabs cost S x N x K x 8 bytes of traffic
+    // 1 - 1.5 blocks per CU measured best on MI355X (256 CUs): more splits only add slab traffic (S x N x K x 8 bytes)
+    const int target = tiles <= 16 ? 256 : 384;
+    int s = cdiv(target, tiles);
     const int max_s = cdiv(M, 8 * step);       // at least 8 reduction steps per split
     if (s > max_s) s = max_s;
     if (s < 1) s = 1;
