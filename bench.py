@@ -43,6 +43,30 @@ def parse():
     return ap.parse_args()
 
 
+# kernel family (ops.Profiler tag) -> kernel-name prefixes in the rocprofv3 PMC summary committed under profiles/
+_FAMILY_KERNELS = {"gemm_nt": ("void gemm_nt_fast_kernel", "void gemm_nt_kernel"), "gemm_wgrad": ("void gemm_tn_", "wgrad_reduce_kernel"),
+                   "attn_fwd": ("void attn_fwd_",), "attn_bwd": ("void attn_bwd_", "void attn_delta_"),
+                   "layernorm_fwd": ("void ln_fwd_",), "layernorm_bwd": ("void ln_bwd_", "ln_bwd_reduce"),
+                   "ce_argmax": ("void ce_argmax_",), "warp_fuse": ("warp_fuse_", "wf_pack_bits")}
+
+
+def _pmc_traffic(family):
+    """HBM-side bytes per launch of the family's kernels from the committed PMC summary (tools/pmc_traffic.sh: separate
+    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this same bench command, gfx950 FETCH_SIZE correction applied).
+    Counters cannot be collected inside the timed run, so this is read from profiles/; None if the file is absent."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    if not os.path.exists(path) or family not in _FAMILY_KERNELS:
+        return None
+    with open(path) as f:
+        kernels = json.load(f)["kernels"]
+    tot, n = 0.0, 0
+    for name, v in kernels.items():
+        if name.startswith(_FAMILY_KERNELS[family]):
+            tot += (v["fetch_bytes_per_launch"] + v["write_bytes_per_launch"]) * v["launches"]
+            n += v["launches"] if not name.startswith(("wgrad_reduce", "ln_bwd_reduce", "void attn_delta_", "wf_pack_bits")) else 0
+    return round(tot / n) if n else None
+
+
 def cpu_baseline(args, cores):
     """The CPU oracle's training step (fp32 PyTorch-CPU restatement of the reference path + AdamW) on ONE
     synthetic scene of the same law; 1 warm-up + 2 timed steps (about 10-20 s)."""
@@ -149,7 +173,10 @@ def main():
         elapsed = tmax.item()
     if rank == 0:
         value = frames_per_step * world * args.steps / elapsed
-        if prof["flops"] > 0:
+        peak_f = PEAK_BF16_TFLOPS if args.dtype == "bf16" else 157.3
+        # the resource that bounds the family: time at peak MFMA rate vs time at peak HBM rate for its algorithmic work
+        mfma_bound = prof["flops"] > 0 and prof["flops"] / (peak_f * 1e12) >= prof["bytes"] / (PEAK_HBM_GBS * 1e9)
+        if mfma_bound:
             ach = prof["flops"] / (prof["ms"] * 1e-3) / 1e12
             roof = {"kernel": dominant, "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS if args.dtype == "bf16" else 157.3,
                     "unit": "TFLOP/s", "frac": round(ach / (PEAK_BF16_TFLOPS if args.dtype == "bf16" else 157.3), 4), "traffic": None,
@@ -159,7 +186,14 @@ def main():
             ach = prof["bytes"] / (prof["ms"] * 1e-3) / 1e9
             roof = {"kernel": dominant, "bound": "hbm", "achieved": round(ach, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                     "frac": round(ach / PEAK_HBM_GBS, 4), "traffic": None, "launches_per_step": prof["launches"] // args.steps,
-                    "avg_launch_us": round(1e3 * prof["ms"] / prof["launches"], 2)}
+                    "avg_launch_us": round(1e3 * prof["ms"] / prof["launches"], 2),
+                    "share_of_step": round(prof["ms"] / args.steps / (1e3 * elapsed / args.steps), 3),
+                    "mfma_tflops": round(prof["flops"] / (prof["ms"] * 1e-3) / 1e12, 1)}
+        roof["algorithmic_bytes_per_launch"] = round(prof["bytes"] / prof["launches"])
+        roof["algorithmic_flops_per_launch"] = round(prof["flops"] / prof["launches"])
+        traffic = _pmc_traffic(dominant)
+        if traffic is not None:
+            roof["traffic"] = traffic
         if args.profile_all:
             tot = sum(v["ms"] for v in probe.values())
             for k, v in sorted(probe.items(), key=lambda kv: -kv[1]["ms"]):

@@ -178,7 +178,11 @@ def gemm(a, w, m=None, bias=None, act=ACT_NONE, res=None, res_mod=0, res2=None, 
     pre = torch.empty(rows_out, n, dtype=a.dtype, device=dev) if want_pre else None
     g = L.StarGemm(p(a), p(w), p(a_rows), p(c_rows), p(bias), p(res), res_mod, p(res2), res2_div, res2_mod, p(aux), act,
                    p(pre), p(out_lp), p(out_f32), m, n, k, dt, flags)
-    with _timed("gemm_nt", 2.0 * m * n * k):
+    esz = a.element_size()
+    nbytes = (m * k + n * k) * esz + rows_out * n * ((esz if out_lp is not None else 0) + (4 if out_f32 is not None else 0) +
+                                                      (esz if pre is not None else 0)) + m * n * ((4 if res is not None else 0) +
+                                                                                                 (esz if aux is not None else 0))
+    with _timed("gemm_nt", 2.0 * m * n * k, float(nbytes)):   # algorithmic bytes: every operand and result once
         L.check(L.lib().star_gemm(C.byref(g), L.stream()))
     return out_lp, out_f32, pre
 
@@ -198,7 +202,7 @@ def gemm_wgrad(dy, x, x_rows=None, want_bias=True, want_weight=True, dw=None, db
     assert dw is None or (dw.is_contiguous() and dw.numel() == n * k)
     assert db is None or (db.is_contiguous() and db.numel() == n)
     ws = torch.empty(L.lib().star_gemm_wgrad_ws(m, n, k), dtype=torch.float32, device=dev)
-    with _timed("gemm_wgrad", 2.0 * m * n * k):
+    with _timed("gemm_wgrad", 2.0 * m * n * k, float(m * (n + k) * dy.element_size() + n * k * 4)):
         L.check(L.lib().star_gemm_wgrad(p(dy), p(x), p(x_rows), p(dw), p(db), p(ws), m, n, k, dt, L.stream()))
     return dw, db
 
