@@ -207,7 +207,14 @@ __device__ __forceinline__ void tr_wait(short4_t (&lo)[4], short4_t (&hi)[4]) {
 
 // Forward.  Stage (ring of 3) = K image | V image | [hd 16: 2 KiB of bf16 ones].  The softmax denominator comes
 // out of the matrix pipe: a ones row block appended to V^T (hd 16: the idle MFMA rows 16..31 read the ones area;
-// hd >= 32: one extra MFMA chain) -- the vector ALU, which bounds this kernel, only does max, fma, exp2, cvt.
+// hd >= 32: four in-register add chains, cheaper than an extra MFMA chain on the busy matrix pipe).
+#ifdef ATT_STAMP
+__device__ unsigned long long g_stamps[16 * 8];
+#define STAMP(k) do { __builtin_amdgcn_sched_barrier(0); if (stamp_on && it >= 8 && it < 10) { unsigned long long t_; asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(t_)); stv[(it - 8) * 8 + (k)] = t_; } __builtin_amdgcn_sched_barrier(0); } while (0)
+extern "C" int star_debug_stamps(unsigned long long* host) { return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_stamps), sizeof(g_stamps)); }
+#else
+#define STAMP(k) do {} while (0)
+#endif
 template <int HD>
 __global__ __launch_bounds__(AT) void attn_fwd_bf16_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
                                                            float* __restrict__ lse, int L, int H, float c) {
@@ -256,9 +263,8 @@ __global__ __launch_bounds__(AT) void attn_fwd_bf16_kernel(const bf16_t* __restr
         for (int j = 0; j < NI; ++j) dma16(rsrc, smem + stage * STAGE + dst[j], src[j] + (unsigned)t * tile_step);
     };
 
-    f32x16_t o[C::DB], lacc;
-#pragma unroll
-    for (int e = 0; e < 16; ++e) lacc[e] = 0.f;
+    f32x16_t o[C::DB];
+    float lsum[4] = {0.f, 0.f, 0.f, 0.f};   // hd >= 32: row sums as four independent add chains (hd 16: out of the matrix pipe)
 #pragma unroll
     for (int db = 0; db < C::DB; ++db)
 #pragma unroll
@@ -286,14 +292,23 @@ __global__ __launch_bounds__(AT) void attn_fwd_bf16_kernel(const bf16_t* __restr
     issue(0, 0);
     if (nt > 1) issue(1, 1);
     int stage = 0;
+#ifdef ATT_STAMP
+    const bool stamp_on = wave == 0 && blockIdx.x == 1000 && HD == 32;
+    unsigned long long stv[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) stv[k] = 0;
+#endif
     for (int it = 0; it < nt; ++it) {
+        STAMP(0);
         if (it + 1 < nt) wait_vm<NI>(); else wait_vm<0>();
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
+        STAMP(1);
         if (it + 2 < nt) issue(it + 2, stage >= 1 ? stage - 1 : 2);
         const unsigned char* st = smem + stage * STAGE;
         const unsigned sbase = lds_base + stage * STAGE;
         stage = stage == 2 ? 0 : stage + 1;
+        STAMP(2);
 
         f32x16_t s[2];
 #pragma unroll
@@ -308,6 +323,7 @@ __global__ __launch_bounds__(AT) void attn_fwd_bf16_kernel(const bf16_t* __restr
         short4_t vlo[C::DB][4], vhi[C::DB][4];
 #pragma unroll
         for (int db = 0; db < C::DB; ++db) tr_issue<C::RB>(sbase + voff[0][db], sbase + voff[1][db], vlo[db], vhi[db]);
+        STAMP(3);
         if ((it + 1) * 64 > L) {   // ragged last tile only (uniform branch)
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb)
@@ -330,6 +346,7 @@ __global__ __launch_bounds__(AT) void attn_fwd_bf16_kernel(const bf16_t* __restr
             if (e + 3 < 16) mx2 = max3(mx2, s[1][e + 2], s[1][e + 3]);
         }
         mx = xor32_max(max3(mx, mx2, s[1][15]));
+        STAMP(4);
         if (__builtin_amdgcn_ballot_w64((mx - m) * c > RESCALE_TH) != 0) {   // rare after the first tiles (uniform branch)
             const float mn = fmaxf(m, mx);
             const float alpha = __builtin_amdgcn_exp2f((m - mn) * c);
@@ -338,15 +355,23 @@ __global__ __launch_bounds__(AT) void attn_fwd_bf16_kernel(const bf16_t* __restr
             for (int db = 0; db < C::DB; ++db)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) o[db][e] *= alpha;
-            if constexpr (HD >= 32) lacc[0] *= alpha;
+            if constexpr (HD >= 32) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) lsum[u] *= alpha;
+            }
         }
         const float mc = m * c;
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) s[kb][e] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kb][e], c, -mc));
+            for (int e = 0; e < 16; ++e) {
+                s[kb][e] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kb][e], c, -mc));
+                if constexpr (HD >= 32) lsum[e & 3] += s[kb][e];
+            }
+        STAMP(5);
         tr_wait(vlo[0], vhi[0]);
         if constexpr (C::DB == 2) tr_wait(vlo[1], vhi[1]);
+        STAMP(6);
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
@@ -357,10 +382,18 @@ __global__ __launch_bounds__(AT) void attn_fwd_bf16_kernel(const bf16_t* __restr
                     const short4_t lo = vlo[db][kb * 2 + s2], hi = vhi[db][kb * 2 + s2];
                     o[db] = mfma32((short8_t){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]}, pf, o[db]);
                 }
-                if constexpr (HD >= 32) lacc = mfma32(ONES8, pf, lacc);
             }
+        STAMP(7);
     }
-    const float l = HD == 16 ? o[0][8] : lacc[0];
+#ifdef ATT_STAMP
+    if (stamp_on && lane == 0)
+        for (int k = 0; k < 16; ++k) g_stamps[k] = stv[k];
+#endif
+    float l = o[0][8];   // hd 16: the ones rows of V^T hold the row sums (both lane halves already combined by the MFMA)
+    if constexpr (HD >= 32) {
+        l = (lsum[0] + lsum[1]) + (lsum[2] + lsum[3]);
+        l += __shfl_xor(l, 32, 64);
+    }
     if (h2 == 0 && q < L) lse[((int64_t)nb * H + h) * L + q] = m * c + log2f(l);
     __syncthreads();   // every wave is done with the ring before it becomes the store staging area
     store_T<HD>(o, 1.0f / l, smem + wave * 32 * C::RB, out + ((int64_t)nb * L + q0) * H * HD + h * HD, (int64_t)H * HD, L - q0, lane);
