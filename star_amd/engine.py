@@ -10,6 +10,7 @@ Row conventions (all matrices are [rows, features], rows contiguous):
   compressed row r = f*keep + j
 """
 import math
+import os
 
 import torch
 
@@ -17,6 +18,7 @@ from . import ops
 from ._lib import ACT_DRELU, ACT_GELU, ACT_MULAUX, ACT_NONE, ACT_RELU, BF16, F32, GEMM_PRE_IS_GRAD, GEMM_RES_BY_AROW
 
 _LINEARS_BLOCK = ("attn.qkv", "attn.proj", "mlp.fc1", "mlp.fc2")
+SIDE_STREAM = os.environ.get("STAR_AMD_SIDE_STREAM", "1") != "0"   # weight gradients on a second stream
 
 
 class Config:
@@ -43,13 +45,20 @@ class Config:
         self.V = self.chans * self.patch * self.patch
 
 
+_HEAD_PERM = {}
+
+
 def head_permutation(cfg, device):
     """Row order of the fused prediction-head weight.  Reference rows are (py, px, c) per class
     (mae_base.py:392-406 un-patchify order); the kernels want class-major (c, py, px) so that the 8
     voxels of a patch row are contiguous.  Returns idx with new_row[n] = old_row[idx[n]]."""
     p, c = cfg.patch, cfg.chans
-    cc, py, px = torch.meshgrid(torch.arange(c), torch.arange(p), torch.arange(p), indexing="ij")
-    return ((py * p + px) * c + cc).reshape(-1).to(device)
+    key = (p, c, str(device))
+    idx = _HEAD_PERM.get(key)
+    if idx is None:   # built once: a host-to-device copy in the middle of the backward pass would stall the launch queue
+        cc, py, px = torch.meshgrid(torch.arange(c), torch.arange(p), torch.arange(p), indexing="ij")
+        idx = _HEAD_PERM[key] = ((py * p + px) * c + cc).reshape(-1).to(device)
+    return idx
 
 
 class Weights:
@@ -185,10 +194,40 @@ def stages(cfg):
     return out
 
 
-def _wg(grads, G, name, dy, x, x_rows=None):
+class _SideStream:
+    """Weight-gradient GEMMs do not feed the rest of the backward chain, so they run on a second HIP stream and
+    share the CUs with the latency-bound kernels of the main chain (attention backward, LayerNorm).  `join` makes
+    the caller's stream wait for everything issued here (before a gradient bucket is reduced / the step ends)."""
+    streams = {}
+
+    def __init__(self, device):
+        self.device = device
+        self.stream = _SideStream.streams.setdefault(device, torch.cuda.Stream(device=device))
+        self.used = False
+
+    def run(self, fn, *tensors):
+        main = torch.cuda.current_stream(self.device)
+        self.stream.wait_stream(main)                 # inputs are produced on the caller's stream
+        with torch.cuda.stream(self.stream):
+            out = fn()
+        for t in tensors:
+            if t is not None:
+                t.record_stream(self.stream)          # keep the caching allocator from recycling them early
+        self.used = True
+        return out
+
+    def join(self):
+        if self.used:
+            torch.cuda.current_stream(self.device).wait_stream(self.stream)
+            self.used = False
+
+
+def _wg(grads, G, name, dy, x, x_rows=None, side=None):
     """weight + bias gradient of Linear `name`, written into the caller's gradient views when given."""
-    dw, db = ops.gemm_wgrad(dy, x, x_rows=x_rows, dw=None if G is None else G[name + ".weight"],
-                            db=None if G is None else G[name + ".bias"])
+    def run():
+        return ops.gemm_wgrad(dy, x, x_rows=x_rows, dw=None if G is None else G[name + ".weight"],
+                              db=None if G is None else G[name + ".bias"])
+    dw, db = run() if side is None else side.run(run, dy, x, x_rows)
     grads[name + ".weight"], grads[name + ".bias"] = dw, db
 
 
@@ -200,19 +239,19 @@ def _ln_bwd(grads, G, name, dy, x, P, mean, rstd, g_in=None):
     return g, g_lp
 
 
-def _block_bwd(g, g_lp, s, P, W, dt, grads, G=None):
+def _block_bwd(g, g_lp, s, P, W, dt, grads, G=None, side=None):
     pre = s["pre"]
     heads, nb, l = s["heads"], s["nb"], s["l"]
     hd = s["x"].shape[1] // heads
-    _wg(grads, G, pre + "mlp.fc2", g_lp, s["v"])
+    _wg(grads, G, pre + "mlp.fc2", g_lp, s["v"], side=side)
     du, _, _ = ops.gemm(g_lp, _lin(P, W, pre + "mlp.fc2", dt, True), act=ACT_MULAUX, aux=s["u"])
-    _wg(grads, G, pre + "mlp.fc1", du, s["h2"])
+    _wg(grads, G, pre + "mlp.fc1", du, s["h2"], side=side)
     dh2, _, _ = ops.gemm(du, _lin(P, W, pre + "mlp.fc1", dt, True))
     g1, g1_lp = _ln_bwd(grads, G, pre + "norm2", dh2, s["x_mid"], P, s["mean2"], s["rstd2"], g_in=g)
-    _wg(grads, G, pre + "attn.proj", g1_lp, s["a"])
+    _wg(grads, G, pre + "attn.proj", g1_lp, s["a"], side=side)
     da, _, _ = ops.gemm(g1_lp, _lin(P, W, pre + "attn.proj", dt, True))
     dqkv = ops.attn_bwd(s["qkv"], s["a"], da, s["lse"], nb, l, heads, hd)
-    _wg(grads, G, pre + "attn.qkv", dqkv, s["h1"])
+    _wg(grads, G, pre + "attn.qkv", dqkv, s["h1"], side=side)
     dh1, _, _ = ops.gemm(dqkv, _lin(P, W, pre + "attn.qkv", dt, True))
     g0, g0_lp = _ln_bwd(grads, G, pre + "norm1", dh1, s["x"], P, s["mean1"], s["rstd1"], g_in=g1)
     return g0, g0_lp
@@ -304,7 +343,7 @@ def forward(cfg, P, W, dt, imgs1, imgs_next, trans_matrices, num_agent, batch, m
     ce = ops.ce_argmax(logits, imgs1, p, dt, want_pred=taps is not None, want_dlogits=train)
     if taps is not None:
         taps["pred"], taps["mask"], taps["ids_restore"] = ce["pred"], mask, ids_restore
-    theta = ops.warp_thetas(trans_matrices).to(dev, non_blocking=True)
+    theta = ops.warp_thetas(trans_matrices).pin_memory().to(dev, non_blocking=True)   # pinned: the copy does not block the host
     na = num_agent if num_agent.is_cuda else num_agent.to(dev)
     if na.dtype not in (torch.int32, torch.int64):
         na = na.long()
@@ -330,6 +369,7 @@ def backward(cfg, P, W, dt, ctx, G=None, on_ready=None):
     grads = {}
     save = ctx["save"]
     dlog = ctx["dlogits"]
+    side = _SideStream(dlog.device) if SIDE_STREAM and G is not None else None
     # prediction heads
     dw, db = ops.gemm_wgrad(dlog, ctx["yd"])
     idx = head_permutation(cfg, dw.device)
@@ -347,9 +387,11 @@ def backward(cfg, P, W, dt, ctx, G=None, on_ready=None):
     if on_ready is not None:
         on_ready(stage)
     for s in reversed(save[cfg.depth:]):
-        g, g_lp = _block_bwd(g, g_lp, s, P, W, dt, grads, G)
+        g, g_lp = _block_bwd(g, g_lp, s, P, W, dt, grads, G, side)
         stage += 1
         if on_ready is not None:
+            if side is not None:
+                side.join()
             on_ready(stage)
     # temporal un-mixing backward: g is d/d(decoder input rows)
     if ctx["random_mode"]:
@@ -377,9 +419,11 @@ def backward(cfg, P, W, dt, ctx, G=None, on_ready=None):
     if on_ready is not None:
         on_ready(stage)
     for s in reversed(save[:cfg.depth]):
-        g, g_lp = _block_bwd(g, g_lp, s, P, W, dt, grads, G)
+        g, g_lp = _block_bwd(g, g_lp, s, P, W, dt, grads, G, side)
         stage += 1
         if on_ready is not None:
+            if side is not None:
+                side.join()
             on_ready(stage)
     # patch embedding
     wshape = P["patch_embed.proj.weight"].shape
@@ -392,6 +436,8 @@ def backward(cfg, P, W, dt, ctx, G=None, on_ready=None):
         dw = dw.reshape(wshape[0], wshape[2], wshape[3], wshape[1]).permute(0, 3, 1, 2).contiguous()
     _put(grads, G, "patch_embed.proj.weight", dw.reshape(wshape))
     _put(grads, G, "patch_embed.proj.bias", db)
+    if side is not None:
+        side.join()
     if on_ready is not None:
         on_ready(stage + 1)
     return grads
