@@ -197,10 +197,21 @@ template <int RB> __device__ __forceinline__ void tr_issue(unsigned a_lo, unsign
     lo[2] = tr16<32 * RB>(a_lo);  hi[2] = tr16<32 * RB>(a_hi);
     lo[3] = tr16<48 * RB>(a_lo);  hi[3] = tr16<48 * RB>(a_hi);
 }
+// two 16-row k-slices (32 rows) only
+template <int RB> __device__ __forceinline__ void tr_issue_half(unsigned a_lo, unsigned a_hi, short4_t (&lo)[2], short4_t (&hi)[2]) {
+    lo[0] = tr16<0>(a_lo);        hi[0] = tr16<0>(a_hi);
+    lo[1] = tr16<16 * RB>(a_lo);  hi[1] = tr16<16 * RB>(a_hi);
+}
+__device__ __forceinline__ void tr_wait_half(short4_t (&a)[2], short4_t (&b)[2], short4_t (&c)[2], short4_t (&d)[2]) {
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(a[0]), "+v"(a[1]), "+v"(b[0]), "+v"(b[1]), "+v"(c[0]), "+v"(c[1]), "+v"(d[0]), "+v"(d[1]));
+}
 __device__ __forceinline__ void tr_wait(short4_t (&lo)[4], short4_t (&hi)[4]) {
     asm volatile("s_waitcnt lgkmcnt(0)"
                  : "+v"(lo[0]), "+v"(lo[1]), "+v"(lo[2]), "+v"(lo[3]), "+v"(hi[0]), "+v"(hi[1]), "+v"(hi[2]), "+v"(hi[3]));
 }
+
+__device__ __forceinline__ short8_t join8(short4_t lo, short4_t hi) { return (short8_t){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]}; }
 
 #define ONES8 ((short8_t){0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80})
 #define RESCALE_TH 8.0f   // log2 units: the running reference maximum is only raised when a row exceeds it by 2^8
@@ -208,45 +219,45 @@ __device__ __forceinline__ void tr_wait(short4_t (&lo)[4], short4_t (&hi)[4]) {
 // Forward.  Stage (ring of 3) = K image | V image | [hd 16: 2 KiB of bf16 ones].  The softmax denominator comes
 // out of the matrix pipe: a ones row block appended to V^T (hd 16: the idle MFMA rows 16..31 read the ones area;
 // hd >= 32: four in-register add chains, cheaper than an extra MFMA chain on the busy matrix pipe).
-#ifdef ATT_STAMP
-__device__ unsigned long long g_stamps[16 * 8];
-#define STAMP(k) do { __builtin_amdgcn_sched_barrier(0); if (stamp_on && it >= 8 && it < 10) { unsigned long long t_; asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(t_)); stv[(it - 8) * 8 + (k)] = t_; } __builtin_amdgcn_sched_barrier(0); } while (0)
-extern "C" int star_debug_stamps(unsigned long long* host) { return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_stamps), sizeof(g_stamps)); }
-#else
-#define STAMP(k) do {} while (0)
-#endif
-template <int HD>
+template <int HD, int QB>
 __global__ __launch_bounds__(AT) void attn_fwd_bf16_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
                                                            float* __restrict__ lse, int L, int H, float c) {
     using C = ACfg<HD>;
     constexpr int NI = 2 * C::NP / 4;                           // DMA instructions per wave per tile
     constexpr int STAGE = 2 * C::TILE + (HD == 16 ? 2048 : 0);
+    constexpr int QW = 32 * QB, QBLK = 4 * QW;                  // queries per wave / per block
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    // XCD-aware work order: the L/128 row blocks of one (sequence, head) stream the same K/V (Q/dO) tiles, so they
+    // XCD-aware work order: the row blocks of one (sequence, head) stream the same K/V (Q/dO) tiles, so they
     // run back to back on ONE XCD and share its L2 instead of fetching the tiles into all eight
-    const int nrb = (L + 127) >> 7;
+    const int nrb = (L + QBLK - 1) / QBLK;
     const int work = xcd_remap(blockIdx.x, gridDim.x);
     const int rblk = work % nrb, h = (work / nrb) % H, nb = work / (nrb * H);
     const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h2 = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int64_t rs = (int64_t)3 * H * HD;
     const bf16_t* qb = qkv + (int64_t)nb * L * rs + h * HD;
-    const int q0 = rblk * 128 + wave * 32;
-    const int q = q0 + r;
+    const int q0 = rblk * QBLK + wave * QW;   // the wave's QB query blocks of 32 rows start here
 
-    short8_t qf[C::KS];
+    // QB query blocks per wave share every K fragment and V^T fragment read from LDS, every tile DMA and barrier, and
+    // give the in-order wave independent MFMA / softmax chains to interleave
+    short8_t qf[QB][C::KS];
 #pragma unroll
-    for (int ks = 0; ks < C::KS; ++ks) {
-        qf[ks] = (short8_t){0, 0, 0, 0, 0, 0, 0, 0};
-        if (q < L) qf[ks] = *reinterpret_cast<const short8_t*>(qb + (int64_t)q * rs + ks * 16 + 8 * h2);
-    }
+    for (int qi = 0; qi < QB; ++qi)
+#pragma unroll
+        for (int ks = 0; ks < C::KS; ++ks) {
+            const int q = q0 + qi * 32 + r;
+            qf[qi][ks] = (short8_t){0, 0, 0, 0, 0, 0, 0, 0};
+            if (q < L) qf[qi][ks] = *reinterpret_cast<const short8_t*>(qb + (int64_t)q * rs + ks * 16 + 8 * h2);
+        }
     if constexpr (HD == 16) {
         for (int i = tid; i < 3 * 128; i += AT) *reinterpret_cast<uint4*>(smem + (i >> 7) * STAGE + 2 * C::TILE + (i & 127) * 16) =
             make_uint4(0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u);
         __syncthreads();
     }
 #pragma unroll
-    for (int ks = 0; ks < C::KS; ++ks) pin(qf[ks]);
+    for (int qi = 0; qi < QB; ++qi)
+#pragma unroll
+        for (int ks = 0; ks < C::KS; ++ks) pin(qf[qi][ks]);
 
     __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(qb), 0, (unsigned)((L * rs - h * HD) * 2), 0x00020000);
     unsigned src[NI];
@@ -263,13 +274,19 @@ __global__ __launch_bounds__(AT) void attn_fwd_bf16_kernel(const bf16_t* __restr
         for (int j = 0; j < NI; ++j) dma16(rsrc, smem + stage * STAGE + dst[j], src[j] + (unsigned)t * tile_step);
     };
 
-    f32x16_t o[C::DB];
-    float lsum[4] = {0.f, 0.f, 0.f, 0.f};   // hd >= 32: row sums as four independent add chains (hd 16: out of the matrix pipe)
+    f32x16_t o[QB][C::DB];
+    float lsum[QB][4];        // hd >= 32: row sums as four independent add chains (hd 16: out of the matrix pipe)
+    float m[QB];              // reference maximum the exponentials are taken against (raw score units)
 #pragma unroll
-    for (int db = 0; db < C::DB; ++db)
+    for (int qi = 0; qi < QB; ++qi) {
+        m[qi] = -INFINITY;
 #pragma unroll
-        for (int e = 0; e < 16; ++e) o[db][e] = 0.f;
-    float m = -INFINITY;      // reference maximum the exponentials are taken against (raw score units)
+        for (int u = 0; u < 4; ++u) lsum[qi][u] = 0.f;
+#pragma unroll
+        for (int db = 0; db < C::DB; ++db)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) o[qi][db][e] = 0.f;
+    }
 
     // per-lane fragment offsets inside a stage
     int koff[C::KS];
@@ -292,111 +309,107 @@ __global__ __launch_bounds__(AT) void attn_fwd_bf16_kernel(const bf16_t* __restr
     issue(0, 0);
     if (nt > 1) issue(1, 1);
     int stage = 0;
-#ifdef ATT_STAMP
-    const bool stamp_on = wave == 0 && blockIdx.x == 1000 && HD == 32;
-    unsigned long long stv[16];
-#pragma unroll
-    for (int k = 0; k < 16; ++k) stv[k] = 0;
-#endif
     for (int it = 0; it < nt; ++it) {
-        STAMP(0);
         if (it + 1 < nt) wait_vm<NI>(); else wait_vm<0>();
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        STAMP(1);
         if (it + 2 < nt) issue(it + 2, stage >= 1 ? stage - 1 : 2);
         const unsigned char* st = smem + stage * STAGE;
         const unsigned sbase = lds_base + stage * STAGE;
         stage = stage == 2 ? 0 : stage + 1;
-        STAMP(2);
 
-        f32x16_t s[2];
+        f32x16_t s[QB][2];
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
 #pragma unroll
-            for (int e = 0; e < 16; ++e) s[kb][e] = 0.f;
+            for (int qi = 0; qi < QB; ++qi)
 #pragma unroll
-            for (int ks = 0; ks < C::KS; ++ks)
-                s[kb] = mfma32(*reinterpret_cast<const short8_t*>(st + koff[ks] + kb * 32 * C::RB), qf[ks], s[kb]);
+                for (int e = 0; e < 16; ++e) s[qi][kb][e] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < C::KS; ++ks) {
+                const short8_t kf = *reinterpret_cast<const short8_t*>(st + koff[ks] + kb * 32 * C::RB);
+#pragma unroll
+                for (int qi = 0; qi < QB; ++qi) s[qi][kb] = mfma32(kf, qf[qi][ks], s[qi][kb]);
+            }
         }
         // V^T fragments for the whole tile: issued now, waited on just before the PV products
         short4_t vlo[C::DB][4], vhi[C::DB][4];
 #pragma unroll
         for (int db = 0; db < C::DB; ++db) tr_issue<C::RB>(sbase + voff[0][db], sbase + voff[1][db], vlo[db], vhi[db]);
-        STAMP(3);
         if ((it + 1) * 64 > L) {   // ragged last tile only (uniform branch)
+#pragma unroll
+            for (int qi = 0; qi < QB; ++qi)
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const int key = it * 64 + kb * 32 + (e & 3) + 8 * (e >> 2) + 4 * h2;
+                        if (key >= L) s[qi][kb][e] = -INFINITY;
+                    }
+        }
+#pragma unroll
+        for (int qi = 0; qi < QB; ++qi) {
+            float mx = max3(s[qi][0][0], s[qi][0][1], s[qi][1][0]);
+            float mx2 = max3(s[qi][1][1], s[qi][0][2], s[qi][0][3]);
+#pragma unroll
+            for (int e = 4; e < 16; e += 4) {
+                mx = max3(mx, s[qi][0][e], s[qi][0][e + 1]);
+                mx2 = max3(mx2, s[qi][0][e + 2], s[qi][0][e + 3]);
+            }
+#pragma unroll
+            for (int e = 2; e < 16; e += 4) {
+                mx = max3(mx, s[qi][1][e], s[qi][1][e + 1]);
+                if (e + 3 < 16) mx2 = max3(mx2, s[qi][1][e + 2], s[qi][1][e + 3]);
+            }
+            mx = xor32_max(max3(mx, mx2, s[qi][1][15]));
+            if (__builtin_amdgcn_ballot_w64((mx - m[qi]) * c > RESCALE_TH) != 0) {   // rare after the first tiles (uniform branch)
+                const float mn = fmaxf(m[qi], mx);
+                const float alpha = __builtin_amdgcn_exp2f((m[qi] - mn) * c);
+                m[qi] = mn;
+#pragma unroll
+                for (int db = 0; db < C::DB; ++db)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) o[qi][db][e] *= alpha;
+                if constexpr (HD >= 32) {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) lsum[qi][u] *= alpha;
+                }
+            }
+            const float mc = m[qi] * c;
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
-                    const int key = it * 64 + kb * 32 + (e & 3) + 8 * (e >> 2) + 4 * h2;
-                    if (key >= L) s[kb][e] = -INFINITY;
+                    s[qi][kb][e] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[qi][kb][e], c, -mc));
+                    if constexpr (HD >= 32) lsum[qi][e & 3] += s[qi][kb][e];
                 }
         }
-        float mx = max3(s[0][0], s[0][1], s[1][0]);
-        float mx2 = max3(s[1][1], s[0][2], s[0][3]);
-#pragma unroll
-        for (int e = 4; e < 16; e += 4) {
-            mx = max3(mx, s[0][e], s[0][e + 1]);
-            mx2 = max3(mx2, s[0][e + 2], s[0][e + 3]);
-        }
-#pragma unroll
-        for (int e = 2; e < 16; e += 4) {
-            mx = max3(mx, s[1][e], s[1][e + 1]);
-            if (e + 3 < 16) mx2 = max3(mx2, s[1][e + 2], s[1][e + 3]);
-        }
-        mx = xor32_max(max3(mx, mx2, s[1][15]));
-        STAMP(4);
-        if (__builtin_amdgcn_ballot_w64((mx - m) * c > RESCALE_TH) != 0) {   // rare after the first tiles (uniform branch)
-            const float mn = fmaxf(m, mx);
-            const float alpha = __builtin_amdgcn_exp2f((m - mn) * c);
-            m = mn;
-#pragma unroll
-            for (int db = 0; db < C::DB; ++db)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) o[db][e] *= alpha;
-            if constexpr (HD >= 32) {
-#pragma unroll
-                for (int u = 0; u < 4; ++u) lsum[u] *= alpha;
-            }
-        }
-        const float mc = m * c;
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                s[kb][e] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kb][e], c, -mc));
-                if constexpr (HD >= 32) lsum[e & 3] += s[kb][e];
-            }
-        STAMP(5);
         tr_wait(vlo[0], vhi[0]);
         if constexpr (C::DB == 2) tr_wait(vlo[1], vhi[1]);
-        STAMP(6);
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2) {
-                const bf16x8_t pf = cvt8(s[kb], s2);
+            for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
                 for (int db = 0; db < C::DB; ++db) {
-                    const short4_t lo = vlo[db][kb * 2 + s2], hi = vhi[db][kb * 2 + s2];
-                    o[db] = mfma32((short8_t){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]}, pf, o[db]);
+                    const short8_t vf = join8(vlo[db][kb * 2 + s2], vhi[db][kb * 2 + s2]);
+#pragma unroll
+                    for (int qi = 0; qi < QB; ++qi) o[qi][db] = mfma32(vf, cvt8(s[qi][kb], s2), o[qi][db]);
                 }
-            }
-        STAMP(7);
     }
-#ifdef ATT_STAMP
-    if (stamp_on && lane == 0)
-        for (int k = 0; k < 16; ++k) g_stamps[k] = stv[k];
-#endif
-    float l = o[0][8];   // hd 16: the ones rows of V^T hold the row sums (both lane halves already combined by the MFMA)
-    if constexpr (HD >= 32) {
-        l = (lsum[0] + lsum[1]) + (lsum[2] + lsum[3]);
-        l += __shfl_xor(l, 32, 64);
-    }
-    if (h2 == 0 && q < L) lse[((int64_t)nb * H + h) * L + q] = m * c + log2f(l);
     __syncthreads();   // every wave is done with the ring before it becomes the store staging area
-    store_T<HD>(o, 1.0f / l, smem + wave * 32 * C::RB, out + ((int64_t)nb * L + q0) * H * HD + h * HD, (int64_t)H * HD, L - q0, lane);
+#pragma unroll
+    for (int qi = 0; qi < QB; ++qi) {
+        const int qq = q0 + qi * 32;
+        float l = o[qi][0][8];   // hd 16: the ones rows of V^T hold the row sums (both lane halves already combined by the MFMA)
+        if constexpr (HD >= 32) {
+            l = (lsum[qi][0] + lsum[qi][1]) + (lsum[qi][2] + lsum[qi][3]);
+            l += __shfl_xor(l, 32, 64);
+        }
+        if (h2 == 0 && qq + r < L) lse[((int64_t)nb * H + h) * L + qq + r] = m[qi] * c + log2f(l);
+        if (qi > 0) __syncthreads();   // the staging rows of the previous block have been read
+        store_T<HD>(o[qi], 1.0f / l, smem + wave * 32 * C::RB, out + ((int64_t)nb * L + qq) * H * HD + h * HD, (int64_t)H * HD, L - qq, lane);
+    }
 }
 
 // ws[0][nb][h][l] = sum_d dO * O (bf16 path: negated); bf16 path also ws[1][nb][h][l] = -lse / c, so that the
@@ -428,7 +441,6 @@ __global__ void attn_delta_kernel(const T* __restrict__ out, const T* __restrict
     }
 }
 
-__device__ __forceinline__ short8_t join8(short4_t lo, short4_t hi) { return (short8_t){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]}; }
 
 // dQ: query on the lane (the forward's skeleton and ring).  Stage = K image | V image; K is read by rows for S
 // and transposed for dQ^T += K^T dS^T from the same image.  Keys past L need no mask: their K rows are zero.
@@ -647,14 +659,16 @@ __global__ __launch_bounds__(AT) void attn_bwd_dkv_bf16_kernel(const bf16_t* __r
         const unsigned sbase = lds_base + stage * STAGE;
         stage = stage == 2 ? 0 : stage + 1;
 
-        short4_t qlo[C::DB][4], qhi[C::DB][4], dlo[C::DB][4], dhi[C::DB][4];
-#pragma unroll
-        for (int db = 0; db < C::DB; ++db) {
-            tr_issue<C::RB>(sbase + toff[0][db], sbase + toff[1][db], qlo[db], qhi[db]);
-            tr_issue<C::RB>(sbase + C::TILE + toff[0][db], sbase + C::TILE + toff[1][db], dlo[db], dhi[db]);
-        }
 #pragma unroll
         for (int qblk = 0; qblk < 2; ++qblk) {
+            // transposed Q / dO fragments of this 32-query half: issued now, waited on before the dV / dK products
+            short4_t qlo[C::DB][2], qhi[C::DB][2], dlo[C::DB][2], dhi[C::DB][2];
+#pragma unroll
+            for (int db = 0; db < C::DB; ++db) {
+                const unsigned hb = sbase + qblk * 32 * C::RB;
+                tr_issue_half<C::RB>(hb + toff[0][db], hb + toff[1][db], qlo[db], qhi[db]);
+                tr_issue_half<C::RB>(hb + C::TILE + toff[0][db], hb + C::TILE + toff[1][db], dlo[db], dhi[db]);
+            }
             f32x16_t s, dp;
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
@@ -673,20 +687,15 @@ __global__ __launch_bounds__(AT) void attn_bwd_dkv_bf16_kernel(const bf16_t* __r
                 s[e] = __builtin_amdgcn_exp2f(s[e] * c);
                 dp[e] *= s[e];
             }
-            if (qblk == 0) {
 #pragma unroll
-                for (int db = 0; db < C::DB; ++db) {
-                    tr_wait(qlo[db], qhi[db]);
-                    tr_wait(dlo[db], dhi[db]);
-                }
-            }
+            for (int db = 0; db < C::DB; ++db) tr_wait_half(qlo[db], qhi[db], dlo[db], dhi[db]);
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
                 const bf16x8_t pf = cvt8(s, s2), dsf = cvt8(dp, s2);
 #pragma unroll
                 for (int db = 0; db < C::DB; ++db) {
-                    dv[db] = mfma32(join8(dlo[db][qblk * 2 + s2], dhi[db][qblk * 2 + s2]), pf, dv[db]);
-                    dk[db] = mfma32(join8(qlo[db][qblk * 2 + s2], qhi[db][qblk * 2 + s2]), dsf, dk[db]);
+                    dv[db] = mfma32(join8(dlo[db][s2], dhi[db][s2]), pf, dv[db]);
+                    dk[db] = mfma32(join8(qlo[db][s2], qhi[db][s2]), dsf, dk[db]);
                 }
             }
         }
@@ -862,8 +871,10 @@ template <typename K> static int set_lds(K kernel, size_t bytes) {
 template <int HD>
 static int fwd_bf16(const void* qkv, void* out, float* lse, int NB, int L, int H, float c, hipStream_t s) {
     const size_t lds = 3 * (2 * ACfg<HD>::TILE + (HD == 16 ? 2048 : 0));
-    if (int rc = set_lds(attn_fwd_bf16_kernel<HD>, lds)) return rc;
-    hipLaunchKernelGGL(attn_fwd_bf16_kernel<HD>, dim3(cdiv(L, 128) * H * NB), dim3(AT), lds, s, (const bf16_t*)qkv, (bf16_t*)out, lse, L, H, c);
+    // QB = 2 (two query blocks per wave, K/V fragments shared) measured slower on MI355X: 166 vs 96 VGPRs costs two of
+    // the five waves per SIMD, and occupancy hides more latency here than the extra in-wave parallelism does
+    if (int rc = set_lds(attn_fwd_bf16_kernel<HD, 1>, lds)) return rc;
+    hipLaunchKernelGGL((attn_fwd_bf16_kernel<HD, 1>), dim3(cdiv(L, 128) * H * NB), dim3(AT), lds, s, (const bf16_t*)qkv, (bf16_t*)out, lse, L, H, c);
     return 0;
 }
 template <int HD>
