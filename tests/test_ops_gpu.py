@@ -408,3 +408,28 @@ def test_cast_batch_matches_single_casts():
         for src, dst, tr in jobs:
             want = ops.cast_transpose(src, dt) if tr else ops.cast(src, dt)
             assert torch.equal(dst, want), (src.shape, tr)
+
+
+def test_warp_fuse_full_size_vs_c_oracle():
+    """BASELINE-size maps (256 x 256 x 13, 5 agents, a scene with padded slots) against the plain-C restatement."""
+    from oracle import c_oracle as OC
+    rng = np.random.RandomState(9)
+    B, A, C, S = 2, 5, 13, 256
+    ind = (rng.rand(A * B, C, S, S) < 0.05).astype(np.uint8)
+    trans = np.zeros((B, A, A, 4, 4))
+    for b in range(B):
+        for i in range(A):
+            for j in range(A):
+                yaw, tx, ty = rng.uniform(-math.pi, math.pi), rng.uniform(-20, 20), rng.uniform(-20, 20)
+                trans[b, i, j] = [[math.cos(yaw), -math.sin(yaw), 0, tx], [math.sin(yaw), math.cos(yaw), 0, ty], [0, 0, 1, 0], [0, 0, 0, 1]]
+    na = np.array([[5] * A, [3] * A])
+    want = OC.late_fusion(ind.astype(np.float32), trans, na, B)
+    for binary in (False, True):
+        out = ops.warp_fuse(torch.from_numpy(ind).to(DEV), ops.warp_thetas(torch.from_numpy(trans)).to(DEV), torch.from_numpy(na).to(DEV), B,
+                            binary=binary)
+        assert np.array_equal(out.cpu().numpy(), want), binary
+    ego = (rng.rand(A * B, C, S, S) < 0.05).astype(np.float32)
+    want = OC.late_fusion(ind.astype(np.float32), trans, na, B, ego_maps=ego)
+    out = ops.warp_fuse(torch.from_numpy(ind).to(DEV), ops.warp_thetas(torch.from_numpy(trans)).to(DEV), torch.from_numpy(na).to(DEV), B,
+                        ego=torch.from_numpy(ego).to(DEV), binary=True)
+    assert np.array_equal(out.cpu().numpy(), want)

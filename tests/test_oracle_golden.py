@@ -6,6 +6,7 @@ import pytest
 import torch
 
 from golden_util import GOLD, MODEL_CASES, Case, unpack
+from oracle import c_oracle as OC
 from oracle import star_oracle as O
 
 FP_TOL = dict(rtol=2e-5, atol=2e-5)
@@ -107,3 +108,37 @@ def test_rng_consumption_matches_reference():
         with torch.no_grad():
             O.run(c.sd, cfg, c.bev, c.next, c.trans, c.num_agent, c.B, mask_ratio=c.mask_ratio, taps=taps)
         assert torch.equal(taps["ids_restore"], c.tap("ids_restore"))
+
+
+def test_c_oracle_warp_fusion_matches_reference_goldens():
+    """The plain-C restatement (oracle/star_oracle_c.c) against the same full-resolution reference outputs."""
+    z = np.load(GOLD + "/warp_full256.npz")
+    ind = unpack(z["ind_bits"], z["shape"])
+    gt = unpack(z["gt_bits"], z["shape"])
+    trans, na = z["trans"], z["num_agent"]
+    B = trans.shape[0]
+    assert np.array_equal(OC.late_fusion(ind, trans, na, B), unpack(z["late_bits"], z["shape"]))
+    assert np.array_equal(OC.late_fusion(ind, trans, na, B, ego_maps=gt), unpack(z["ego_bits"], z["shape"]))
+    assert np.array_equal(OC.late_fusion(ind, trans.astype(np.float32), na, B), unpack(z["late32_bits"], z["shape"]))
+
+
+def test_c_oracle_argsort_and_confusion():
+    rng = np.random.RandomState(0)
+    noise = rng.rand(7, 1024).astype(np.float32)
+    noise[:, 100:110] = noise[:, 90:100]          # ties: stable order decides
+    s, inv = OC.shuffle_ids(noise)
+    ts, tinv = O.shuffle_ids(torch.from_numpy(noise))
+    assert np.array_equal(s, ts.numpy()) and np.array_equal(inv, tinv.numpy())
+    checked = 0
+    for name in MODEL_CASES[:4]:                   # ids captured from the reference run
+        z = np.load(GOLD + "/%s.npz" % name)
+        if "noise" in z.files and "tap_ids_restore" in z.files:
+            _, inv = OC.shuffle_ids(z["noise"].reshape(-1, z["noise"].shape[-1]))
+            assert np.array_equal(inv.reshape(z["tap_ids_restore"].shape), z["tap_ids_restore"]), name
+            checked += 1
+    assert checked > 0
+    pred = (rng.rand(3, 13, 64, 64) < 0.3).astype(np.float32)
+    tgt = (rng.rand(3, 13, 64, 64) < 0.3).astype(np.float32)
+    conf = OC.confusion(pred, tgt)
+    want = np.array([[((tgt == t) & (pred == p)).sum() for p in (0, 1)] for t in (0, 1)])
+    assert np.array_equal(conf, want)
