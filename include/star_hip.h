@@ -215,6 +215,21 @@ int star_sumsq(const float* x, int64_t n, float* ws, float* out, void* stream);
 int star_iou_confusion(const float* pred, const float* target, unsigned long long* conf, int N, int Z, int H,
                        int W, void* stream);
 
+/* ---- in front of the path: sparse voxel indices -> dense BEV frames ------------------------------------------
+ * Replaces the dataset's per-frame numpy densification (star/datasets/MultiTempDet.py:134-143, 201-209,
+ * 244-247; MultiTempSeg.py likewise): zeros(dims, bool); v[idx[:,0], idx[:,1], idx[:,2]] = 1; rot90(v, 3);
+ * astype(float32) -- and the dense host->device copy behind it.
+ *   idx       int32 (or int64: idx_is64) [n_points, 3] = (x, y, z) of every occupied voxel, frames back to back
+ *   offsets   int64 [F + 1] on the device: frame f owns points offsets[f] .. offsets[f+1]-1 (empty frames allowed)
+ *   h_offsets optional HOST copy of offsets: lets the call work through the frames in chunks that stay inside the
+ *             256 MiB Infinity Cache (fill, then scatter into the still-resident lines); NULL = one chunk
+ *   out       float32 [F, Y, X, Z] (the reference's channel-last frame; voxel (x,y,z) -> out[y, X-1-x, z]) or,
+ *             with channels_first != 0, [F, Z, Y, X]; written entirely (zero fill + 1.0f per voxel)
+ *   err       optional int32 device word: set to 1 if any index is outside [-dim, dim) (numpy raises IndexError
+ *             there; indices in [-dim, -1] wrap as in numpy); the caller zeroes it. */
+int star_voxel_scatter(const void* idx, int idx_is64, const int64_t* offsets, const int64_t* h_offsets, int64_t n_points,
+                       float* out, int F, int X, int Y, int Z, int channels_first, int32_t* err, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -55,3 +55,17 @@ def confusion(pred, target):
     conf = np.zeros(4, np.int64)
     assert lib().oc_confusion(_p(p), _p(t), C.c_int64(p.size), _p(conf)) == 0
     return conf.reshape(2, 2)
+
+
+def voxel_dense(frames, dims=(256, 256, 13)):
+    """list of [n,3] index arrays -> float32 [F, Y, X, Z] (MultiTempDet.py:134-143 per frame); IndexError like numpy."""
+    counts = [len(f) for f in frames]
+    off = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
+    flat = np.ascontiguousarray(np.concatenate([np.asarray(f, dtype=np.int64).reshape(-1, 3) for f in frames] + [np.zeros((0, 3), np.int64)], 0))
+    x, y, z = dims
+    out = np.empty((len(frames), y, x, z), np.float32)
+    rc = lib().oc_voxel_dense(_p(flat), _p(off), _p(out), len(frames), x, y, z)
+    if rc == -2:
+        raise IndexError("voxel index out of bounds")
+    assert rc == 0
+    return out

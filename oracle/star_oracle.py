@@ -439,3 +439,29 @@ def trainable(sd):
         t.requires_grad_(k not in ("pos_embed", "decoder_pos_embed"))
         out[k] = t
     return out
+
+
+# ---- in front of the path: dataset densification (NEXT row f-2) -----------------------------------------
+def voxel_dense(indices, dims=(256, 256, 13)):
+    """One frame exactly as the dataset builds it (star/datasets/MultiTempDet.py:134-143; the same three
+    statements at :201-209 for the teacher and :244-247 for past frames): zeros(dims, bool), fancy assignment,
+    rot90(k=3), float32.  Parity: these ARE the reference's numpy calls (the dataset class itself cannot be
+    imported -- its base class lives in the absent coperception package -- and the reference holds no data
+    fixture), so numpy's own semantics are the pin: negative indices wrap, out-of-range raises IndexError."""
+    v = np.zeros(dims, dtype=bool)
+    indices = np.asarray(indices).reshape(-1, 3)
+    v[indices[:, 0], indices[:, 1], indices[:, 2]] = 1
+    v = np.rot90(v, 3)
+    return v.astype(np.float32)
+
+
+def past_frames(seq_scenes, idx, time_stamp):
+    """MultiTempDet.py:228-233, statement for statement."""
+    out = []
+    end_frame_idx = - time_stamp + 1 + idx
+    current_scene = seq_scenes[idx]
+    for nextframe_idx in range(idx - 1, end_frame_idx - 1, -1):
+        while nextframe_idx < 0 or seq_scenes[nextframe_idx] != current_scene:
+            nextframe_idx = nextframe_idx + 1
+        out.append(nextframe_idx)
+    return out

@@ -9,6 +9,7 @@
  *                     fusion("union")                star/models/mae_base.py:624-633
  *   oc_argsort_pair   ids_shuffle / ids_restore      star/models/multiagent_mae.py:811-814, mae_base.py:417-421 (stable)
  *   oc_confusion      get_occupancy_IoU confusion    star/utils/metrics.py:14-82 (binary maps, one scale)
+ *   oc_voxel_dense    dataset densification          star/datasets/MultiTempDet.py:134-143 (zeros, fancy assignment, rot90(k=3))
  * Float rules of the warp (every operation rounded once, no contraction: build with -ffp-contract=off):
  *   linspace(-1,1,n) in ATen's two-sided fma form, x (n-1) / n;  [x y 1] theta^T as the k-ordered chain
  *   rn(x*t0), fma(y,t1,.), fma(1,t2,.);  un-normalise ((g+1)*size-1)/2;  rintf (half to even);  zero padding. */
@@ -116,5 +117,31 @@ int oc_argsort_pair(const float* noise, int64_t* ids_shuffle, int64_t* ids_resto
 int oc_confusion(const float* pred, const float* target, int64_t n, int64_t conf[4]) {
     conf[0] = conf[1] = conf[2] = conf[3] = 0;
     for (int64_t e = 0; e < n; ++e) conf[(target[e] != 0.0f) * 2 + (pred[e] != 0.0f)] += 1;
+    return 0;
+}
+
+/* frames of sparse voxel indices -> dense float32 [F, Y, X, Z] as the dataset builds each frame: v[x][y][z] = 1 for
+ * every index row (negative indices wrap once, as numpy's), then rot90(k=3) over axes (0,1): out[i][j] = v[X-1-j][i].
+ * idx int64 [n,3], offsets int64 [F+1].  Returns -2 on an index numpy would reject. */
+int oc_voxel_dense(const int64_t* idx, const int64_t* offsets, float* out, int F, int X, int Y, int Z) {
+    const size_t frame = (size_t)X * Y * Z;
+    unsigned char* v = (unsigned char*)malloc(frame);
+    if (!v) return -1;
+    for (int f = 0; f < F; ++f) {
+        memset(v, 0, frame);
+        for (int64_t p = offsets[f]; p < offsets[f + 1]; ++p) {
+            int64_t x = idx[p * 3], y = idx[p * 3 + 1], z = idx[p * 3 + 2];
+            if (x < 0) x += X;
+            if (y < 0) y += Y;
+            if (z < 0) z += Z;
+            if (x < 0 || x >= X || y < 0 || y >= Y || z < 0 || z >= Z) { free(v); return -2; }
+            v[((size_t)x * Y + y) * Z + z] = 1;
+        }
+        float* o = out + (size_t)f * frame;
+        for (int i = 0; i < Y; ++i)
+            for (int j = 0; j < X; ++j)
+                for (int z = 0; z < Z; ++z) o[((size_t)i * X + j) * Z + z] = (float)v[((size_t)(X - 1 - j) * Y + i) * Z + z];
+    }
+    free(v);
     return 0;
 }

@@ -64,6 +64,7 @@ _SIGS = {
     "star_adamw": (C.c_int, [_P, _P, _P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _I, _P]),
     "star_sumsq": (C.c_int, [_P, _L, _P, _P, _P]),
     "star_iou_confusion": (C.c_int, [_P, _P, _P, _I, _I, _I, _I, _P]),
+    "star_voxel_scatter": (C.c_int, [_P, _I, _P, _P, _L, _P, _I, _I, _I, _I, _I, _P, _P]),
 }
 EXPORTS = tuple(_SIGS)
 

@@ -1,0 +1,1 @@
+from .voxel import SparseSceneDataset, collate_sparse, densify, past_frame_indices, read_sample, write_sample  # noqa: F401

@@ -371,3 +371,29 @@ def iou_confusion(pred, target, conf=None):
         conf = torch.zeros(3, 2, 2, dtype=torch.int64, device=pred.device)
     L.check(L.lib().star_iou_confusion(p(pred), p(target), p(conf), n, z, h, w, L.stream()))
     return conf
+
+
+def voxel_scatter(idx, offsets, dims, channels_first=False, validate=True, out=None, host_offsets=None):
+    """Sparse voxel indices -> dense frames.  idx int32/int64 [n,3] (x,y,z) and offsets int64 [F+1], both on the
+    device; dims = (X, Y, Z).  -> float32 [F, Y, X, Z] (or [F, Z, Y, X]).  validate=True reads back the error word
+    (one host sync) and raises IndexError like numpy's fancy assignment would.  host_offsets: the same offsets as a
+    CPU int64 tensor (the loader has them anyway) -- lets large batches run in cache-sized chunks."""
+    _cuda(idx, offsets)
+    assert offsets.dtype == torch.int64 and offsets.dim() == 1 and offsets.is_contiguous()
+    assert idx.dtype in (torch.int32, torch.int64) and idx.is_contiguous() and (idx.numel() == 0 or (idx.dim() == 2 and idx.shape[1] == 3))
+    f = offsets.numel() - 1
+    x, y, z = dims
+    n = idx.shape[0] if idx.numel() else 0
+    shape = (f, z, y, x) if channels_first else (f, y, x, z)
+    if out is None:
+        out = torch.empty(shape, dtype=torch.float32, device=offsets.device)
+    assert out.dtype == torch.float32 and out.is_contiguous() and tuple(out.shape) == shape
+    err = torch.zeros(1, dtype=torch.int32, device=offsets.device) if validate else None
+    with _timed("voxel_scatter", 0.0, float(f) * x * y * z * 4 + float(n) * (3 * idx.element_size() + 4)):
+        if host_offsets is not None:
+            assert not host_offsets.is_cuda and host_offsets.dtype == torch.int64 and host_offsets.is_contiguous() and host_offsets.numel() == f + 1
+        L.check(L.lib().star_voxel_scatter(p(idx) if n else None, int(idx.dtype == torch.int64), p(offsets), p(host_offsets), n, p(out), f,
+                                           x, y, z, int(channels_first), p(err), L.stream()))
+    if validate and int(err.item()) != 0:
+        raise IndexError("voxel index out of bounds for dims %r" % (tuple(dims),))
+    return out

@@ -101,9 +101,26 @@ def ln_cases():
     return rows
 
 
+def voxel_cases():
+    """Batch of B=8 scenes x 5 agents x (T + teacher) frames, 3 % occupancy: one scatter launch."""
+    import numpy as np
+    rows = []
+    rng = np.random.RandomState(0)
+    for F in (40, 80, 160):
+        n_per = int(0.03 * 256 * 256 * 13)
+        idx = torch.from_numpy(np.stack([rng.randint(0, d, size=F * n_per) for d in (256, 256, 13)], 1).astype(np.int32)).to(dev)
+        off = (torch.arange(F + 1, dtype=torch.int64) * n_per).to(dev)
+        out = torch.empty(F, 256, 256, 13, device=dev)
+        hoff = off.cpu()
+        us = timeit(lambda: ops.voxel_scatter(idx, off, (256, 256, 13), validate=False, out=out, host_offsets=hoff))
+        byt = F * 256 * 256 * 13 * 4 + F * n_per * 16
+        rows.append(("voxel %d fr" % F, F, n_per, us, 0.0, byt / us / 1e3))
+    return rows
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["gemm", "wgrad", "attn", "ln"]
+    which = sys.argv[1:] or ["gemm", "wgrad", "attn", "ln", "voxel"]
     for w in which:
-        rows = dict(gemm=gemm_cases, wgrad=wgrad_cases, attn=attn_cases, ln=ln_cases)[w]()
+        rows = dict(gemm=gemm_cases, wgrad=wgrad_cases, attn=attn_cases, ln=ln_cases, voxel=voxel_cases)[w]()
         for name, a, b, us, tf, gbs in rows:
             print("%-14s %5d %5d  %8.1f us  %7.1f TFLOP/s  %7.1f GB/s(or Gexp/s)" % (name, a, b, us, tf, gbs))
