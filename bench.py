@@ -36,6 +36,7 @@ def parse():
     ap.add_argument("--mask", default="complement", choices=["complement", "random"])
     ap.add_argument("--mask_ratio", type=float, default=0.75)
     ap.add_argument("--model", default="amortized_ind_patch8_light")
+    ap.add_argument("--com", default="ind_mae", choices=["ind_mae", "vqstar"], help="vqstar: the VQ-STAR variant (Makefile sizes K=8192, E=32)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--mode", default="train", choices=["train", "infer"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -121,13 +122,20 @@ def main():
     from star_amd.utils.CoModule import CoModule
 
     torch.manual_seed(0)
-    model = getattr(mm, args.model)(time_stamp=args.time_stamp, mask_method=args.mask).to(dev).set_compute_dtype(args.dtype)
+    if args.com == "vqstar":
+        from star_amd.models import VQSTAR
+        args.model = "vqstar(K=8192,E=32)"
+        model = VQSTAR.vqstar(time_stamp=args.time_stamp, mask_method=args.mask, num_vq_embeddings=8192, vq_embedding_dim=32)
+        model = model.to(dev).set_compute_dtype(args.dtype)
+        opt = FlatAdamW(model, lr=1e-3, betas=(0.9, 0.999), weight_decay=0.0, grouping="flat")
+    else:
+        model = getattr(mm, args.model)(time_stamp=args.time_stamp, mask_method=args.mask).to(dev).set_compute_dtype(args.dtype)
+        opt = FlatAdamW(model, lr=1e-3, betas=(0.9, 0.95), weight_decay=0.05)
     model.train() if args.mode == "train" else model.eval()
-    opt = FlatAdamW(model, lr=1e-3, betas=(0.9, 0.95), weight_decay=0.05)
     par = SceneParallel(model, opt) if world > 1 else None
     if par is not None:
         par.broadcast_parameters(0)
-    cm = CoModule(model, opt, "ind_mae", parallel=par)
+    cm = CoModule(model, opt, args.com, parallel=par)
     data = make_batch(args.batch, args.agents, args.time_stamp, seed=1 + rank, device=dev)   # each rank: its own scenes
     sched = types.SimpleNamespace(lr=1e-3, min_lr=0.0, warmup_epochs=4, nepoch=100)
     frames_per_step = args.batch * args.agents
@@ -138,7 +146,12 @@ def main():
         if args.mode == "train":
             lr_sched.adjust_learning_rate(opt, state["it"] / it_per_epoch + 1, sched)
             torch.manual_seed(123 + state["it"] * world + rank)          # per-rank mask noise stream
-            loss, result, _ = cm.step_mae_completion(data, args.batch, args.mask_ratio, trainable=True)
+            if args.com == "vqstar":
+                loss, result, _, _ = cm.step_vqstar_completion(data, args.batch, args.mask_ratio, trainable=True)
+            else:
+                loss, result, _ = cm.step_mae_completion(data, args.batch, args.mask_ratio, trainable=True)
+        elif args.com == "vqstar":
+            loss = cm.infer_vqstar_completion(data, args.batch, args.mask_ratio)[0]
         else:
             loss, result, _, _ = cm.infer_mae_completion(data, args.batch, args.mask_ratio)
         state["it"] += 1
@@ -212,7 +225,7 @@ def main():
                        "loss": round(float(loss), 6)},
             "roofline": roof,
         }
-        if world == 1 and not args.no_cpu_baseline and args.mode == "train":
+        if world == 1 and not args.no_cpu_baseline and args.mode == "train" and args.com == "ind_mae":
             out["cpu_baseline"] = cpu_baseline(args, min(16, os.cpu_count() or 1))
         print(json.dumps(out), flush=True)
     if world > 1:

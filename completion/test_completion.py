@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""STAR scene-completion evaluation on MI355X -- the `ind_mae` path of the reference's
+"""STAR scene-completion evaluation on MI355X -- the `ind_mae` and `vqstar` paths of the reference's
 completion/test_completion.py: load `checkpoint["model_state_dict"]`, run `infer_mae_completion` (ego slot = the
 agent's own input), accumulate the three-scale occupancy IoU per batch and print the average.
 Synthetic batches stand in for V2X-Sim (see train_completion.py)."""
@@ -11,7 +11,7 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
-from star.models import multiagent_mae  # noqa: E402
+from star.models import VQSTAR, multiagent_mae  # noqa: E402
 from star.utils.CoModule import CoModule  # noqa: E402
 from star.utils.metrics import Metrics  # noqa: E402
 from star_amd.synthetic import make_batch  # noqa: E402
@@ -20,7 +20,12 @@ from star_amd.synthetic import make_batch  # noqa: E402
 def main(args):
     device = torch.device("cuda")
     num_agent = args.num_agent - 1 if args.no_cross_road else args.num_agent
-    model = multiagent_mae.__dict__[args.mae_model](norm_pix_loss=args.norm_pix_loss, time_stamp=args.time_stamp, mask_method=args.mask)
+    if args.com == "vqstar":    # reference test_completion.py:108-113
+        model = VQSTAR.vqstar(norm_pix_loss=args.norm_pix_loss, time_stamp=args.time_stamp, mask_method=args.mask, decay=args.decay,
+                              commitment_cost=args.commitment_cost, num_vq_embeddings=args.num_vq_embeddings,
+                              vq_embedding_dim=args.vq_embedding_dim)
+    else:
+        model = multiagent_mae.__dict__[args.mae_model](norm_pix_loss=args.norm_pix_loss, time_stamp=args.time_stamp, mask_method=args.mask)
     if args.resume:
         checkpoint = torch.load(args.resume, map_location="cpu", weights_only=False)
         model.load_state_dict(checkpoint["model_state_dict"])
@@ -33,7 +38,10 @@ def main(args):
     losses = 0.0
     for it in range(args.iters):
         data = make_batch(args.batch, num_agent, args.time_stamp, seed=10_000 + it, device=device)
-        loss, reconstruction, ind_pred, latent = co_module.infer_mae_completion(data, args.batch, args.mask_ratio)
+        if args.com == "vqstar":
+            loss, reconstruction, ind_pred, perplexity, encodings = co_module.infer_vqstar_completion(data, args.batch, args.mask_ratio)
+        else:
+            loss, reconstruction, ind_pred, latent = co_module.infer_mae_completion(data, args.batch, args.mask_ratio)
         teacher = data["bev_seq_teacher"].squeeze(1).permute(0, 3, 1, 2)
         evaluator.add_batch(reconstruction, teacher.contiguous())
         evaluator.update_IoU()
@@ -58,6 +66,10 @@ if __name__ == "__main__":
     p.add_argument("--time_stamp", default=2, type=int)
     p.add_argument("--mae_model", default="amortized_ind_patch8_light", type=str)
     p.add_argument("--norm_pix_loss", default=False, type=bool)
+    p.add_argument("--decay", default=0., type=float)
+    p.add_argument("--commitment_cost", default=0.25, type=float)
+    p.add_argument("--num_vq_embeddings", default=512, type=int)
+    p.add_argument("--vq_embedding_dim", default=64, type=int)
     p.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     p.add_argument("--iters", default=10, type=int, help="synthetic batches to evaluate")
     main(p.parse_args())

@@ -18,7 +18,7 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
-from star.models import multiagent_mae  # noqa: E402
+from star.models import VQSTAR, multiagent_mae  # noqa: E402
 from star.utils import lr_sched  # noqa: E402
 from star.utils.CoModule import CoModule  # noqa: E402
 from star_amd.optim import FlatAdamW, add_weight_decay  # noqa: E402
@@ -51,21 +51,31 @@ def main(args):
         torch.cuda.set_device(local)
         torch.distributed.init_process_group("nccl", device_id=torch.device("cuda", local))
     device = torch.device("cuda", local)
-    if args.com not in ("ind_mae",):
-        raise ValueError("com: %s is not supported by the MI355X path (use ind_mae)" % args.com)
+    if args.com not in ("ind_mae", "vqstar"):
+        raise ValueError("com: %s is not supported by the MI355X path (use ind_mae or vqstar)" % args.com)
     num_agent = args.num_agent - 1 if args.no_cross_road else args.num_agent
-    model = multiagent_mae.__dict__[args.mae_model](norm_pix_loss=args.norm_pix_loss, time_stamp=args.time_stamp, mask_method=args.mask,
-                                                    encode_partial=args.encode_partial, no_temp_emb=args.no_temp_emb,
-                                                    decode_singletemp=args.decode_singletemp)
+    vq = args.com == "vqstar"
+    if vq:      # reference train_completion.py:93-98,126-128: VQSTAR.vqstar + plain Adam
+        model = VQSTAR.vqstar(norm_pix_loss=args.norm_pix_loss, time_stamp=args.time_stamp, mask_method=args.mask, decay=args.decay,
+                              commitment_cost=args.commitment_cost, num_vq_embeddings=args.num_vq_embeddings,
+                              vq_embedding_dim=args.vq_embedding_dim)
+    else:
+        model = multiagent_mae.__dict__[args.mae_model](norm_pix_loss=args.norm_pix_loss, time_stamp=args.time_stamp, mask_method=args.mask,
+                                                        encode_partial=args.encode_partial, no_temp_emb=args.no_temp_emb,
+                                                        decode_singletemp=args.decode_singletemp)
     model = model.to(device).set_compute_dtype(args.dtype)
     if args.fused_optimizer:
-        optimizer = FlatAdamW(model, lr=args.lr, betas=(0.9, 0.95), weight_decay=args.weight_decay)
+        if vq:
+            optimizer = FlatAdamW(model, lr=args.lr, betas=(0.9, 0.999), weight_decay=0.0, grouping="flat")
+        else:
+            optimizer = FlatAdamW(model, lr=args.lr, betas=(0.9, 0.95), weight_decay=args.weight_decay)
         parallel = SceneParallel(model, optimizer) if world > 1 else None
         if parallel is not None:
             parallel.broadcast_parameters(0)
     else:
         assert world == 1, "multi-GPU training uses the fused optimizer's flat gradient buffer"
-        optimizer = torch.optim.AdamW(add_weight_decay(model, args.weight_decay), lr=args.lr, betas=(0.9, 0.95))
+        optimizer = (torch.optim.Adam(model.parameters(), lr=args.lr) if vq else
+                     torch.optim.AdamW(add_weight_decay(model, args.weight_decay), lr=args.lr, betas=(0.9, 0.95)))
         parallel = None
     co_module = CoModule(model, optimizer, args.com, parallel=parallel)
 
@@ -106,11 +116,16 @@ def main(args):
         for it in range(iters):
             data = make_batch(args.batch, num_agent, args.time_stamp, seed=(epoch * iters + it) * world + rank + 1, device=device)
             lr_sched.adjust_learning_rate(co_module.optimizer, it / iters + epoch, args)
-            loss, reconstruction, _ = co_module.step_mae_completion(data, args.batch, args.mask_ratio, trainable=True)
+            if vq:
+                loss, reconstruction, _, perplexity = co_module.step_vqstar_completion(data, args.batch, args.mask_ratio, trainable=True)
+            else:
+                loss, reconstruction, _ = co_module.step_mae_completion(data, args.batch, args.mask_ratio, trainable=True)
             running.update(loss)
             if it % args.logstep == 0 and rank == 0:
                 print("**Epoch {} -- iterstep {}** : imme loss {:.6f}, running loss {:.6f}, current lr {:.6f}".format(
                     epoch, it, loss, running.avg, co_module.optimizer.param_groups[0]['lr']))
+                if vq:
+                    print("imme perplexity {:.6f}".format(float(perplexity)))
         if saver:
             saver.write("{}\n".format(running))
             saver.flush()
@@ -152,6 +167,10 @@ if __name__ == "__main__":
     p.add_argument("--encode_partial", action="store_true")
     p.add_argument("--no_temp_emb", action="store_true")
     p.add_argument("--decode_singletemp", action="store_true")
+    p.add_argument("--decay", default=0., type=float, help="used in vector quantization")
+    p.add_argument("--commitment_cost", default=0.25, type=float, help="Used in vector quantization")
+    p.add_argument("--num_vq_embeddings", default=512, type=int, help="Used in vector quantization")
+    p.add_argument("--vq_embedding_dim", default=64, type=int, help="Used in vector quantization")
     # extras of the MI355X build
     p.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     p.add_argument("--iters_per_epoch", default=100, type=int, help="synthetic batches per epoch")

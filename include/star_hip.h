@@ -230,6 +230,32 @@ int star_iou_confusion(const float* pred, const float* target, unsigned long lon
 int star_voxel_scatter(const void* idx, int idx_is64, const int64_t* offsets, const int64_t* h_offsets, int64_t n_points,
                        float* out, int F, int X, int Y, int Z, int channels_first, int32_t* err, void* stream);
 
+/* ---- VQ-STAR quantiser (the `--com vqstar` variant of the path) ---------------------------------------------
+ * Replaces STARVectorQuantizer.forward (star/models/mae_base.py:122-173) between compressor and decompressor
+ * (star/models/VQSTAR.py:432,456) and its autograd.
+ * star_vq_assign: x float32 [M, E] (compressor output), codebook float32 [K, E] ->
+ *   idx int64 [M] = argmin_k (|x|^2 + |e_k|^2 - 2 x.e_k) in float32, first minimum;
+ *   q_f32 [M, E] / q_lp [M, E] in `dt` (each optional) = codebook[idx];
+ *   part float32 [star_vq_nblocks(M)] per-workgroup sums of (q - x)^2 (optional);
+ *   counts int32 [K] histogram of idx (optional; zeroed by the call).  E in {8,16,32,64,128}.
+ * star_vq_finish: out3 = {loss = mse + commitment*mse, perplexity = exp(-sum p log(p+1e-10)), mse};
+ *   loss_inout (optional) += loss, in stream order (the model's total loss, VQSTAR.py:443).
+ * star_vq_bwd: dlat `dt` [M, E] = (dq + commitment * 2 (x - q)/(M E)) * [x > 0]  (straight-through estimator
+ *   mae_base.py:166, then the compressor's ReLU); dcodebook float32 [K, E] = 2/(M E) * sum_{idx[m]=k} (q - x[m]),
+ *   summed in a fixed order (deterministic), WRITTEN for every code; needs ws float32 [star_vq_bwd_ws(M,E,K)].
+ *   Either output may be NULL.
+ * star_onehot_rows: the `encodings` matrix the reference returns from inference (mae_base.py:154-155),
+ *   float32 [M, K], K % 4 == 0. */
+int star_vq_nblocks(int M);
+int star_vq_assign(const float* x, const float* codebook, int64_t* idx, float* q_f32, void* q_lp, float* part,
+                   int32_t* counts, int M, int E, int K, int dt, void* stream);
+int star_vq_finish(const float* part, int nblocks, const int32_t* counts, int M, int E, int K, float commitment,
+                   float* out3, float* loss_inout, void* stream);
+int64_t star_vq_bwd_ws(int M, int E, int K);
+int star_vq_bwd(const void* dq, const float* x, const int64_t* idx, const float* codebook, void* dlat,
+                float* dcodebook, float* ws, int M, int E, int K, float commitment, int dt, void* stream);
+int star_onehot_rows(const int64_t* idx, float* out, int M, int K, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -417,10 +417,42 @@ def decode(sd, cfg, latent, mask, ids_restore, taps=None):
     return torch.stack((free, occ), dim=1)
 
 
+def vector_quantize(x, codebook, commitment):
+    """STARVectorQuantizer.forward (star/models/mae_base.py:122-173), decay = 0 variant (the CLI default,
+    completion/train_completion.py:450).  -> (loss, quantized (straight-through), perplexity, indices [M])."""
+    flat = x.reshape(-1, codebook.shape[1])
+    distances = (torch.sum(flat ** 2, dim=1, keepdim=True) + torch.sum(codebook ** 2, dim=1, keepdim=True).t()
+                 - 2 * torch.matmul(flat, codebook.t()))
+    indices = torch.argmin(distances, dim=1)
+    encodings = torch.zeros(indices.shape[0], codebook.shape[0])
+    encodings.scatter_(1, indices.unsqueeze(1), 1)
+    quantized = torch.matmul(encodings, codebook).view(x.shape)
+    e_latent_loss = F.mse_loss(quantized.detach(), x)
+    q_latent_loss = F.mse_loss(quantized, x.detach())
+    loss = q_latent_loss + commitment * e_latent_loss
+    quantized = x + (quantized - x).detach()
+    avg_probs = torch.mean(encodings, dim=0)
+    perplexity = torch.exp(-torch.sum(avg_probs * torch.log(avg_probs + 1e-10)))
+    return loss, quantized, perplexity, indices
+
+
 def run(sd, cfg, imgs1, imgs_next, trans, num_agent, batch, mask_ratio=0.75, infer=False, noise=None, taps=None):
     """forward (multiagent_mae.py:1084-1103) / inference (:1105-1125).
-    Returns (loss, result, latent, ind_result, pred)."""
+    Returns (loss, result, latent, ind_result, pred).  With cfg["vq"] (VQ-STAR, star/models/VQSTAR.py:421-470) the
+    latent is quantised before the decoder, loss = vq + reconstruction, and taps (if given) receives vq_loss,
+    perplexity, vq_indices."""
     latent, mask, ids_restore = encode(sd, cfg, imgs1, imgs_next, mask_ratio, noise, taps)
+    if cfg.get("vq"):
+        vq_loss, quantized, perplexity, vq_idx = vector_quantize(latent, sd["_vq_star._embedding.weight"], cfg["commitment"])
+        pred = decode(sd, cfg, quantized, mask, ids_restore, taps)
+        if taps is not None:
+            taps["mask"], taps["ids_restore"], taps["pred"] = mask, ids_restore, pred
+            taps["vq_loss"], taps["perplexity"], taps["vq_indices"], taps["quantized"] = vq_loss, perplexity, vq_idx, quantized
+        loss = vq_loss + F.cross_entropy(pred, imgs1.long())
+        ind = torch.argmax(torch.softmax(pred.detach(), dim=1), dim=1)
+        fused = late_fusion(ind.numpy().astype(F32), np.asarray(trans), np.asarray(num_agent), batch,
+                            ego_maps=imgs1.detach().numpy() if infer else None)
+        return loss, torch.from_numpy(fused), latent, ind, pred
     pred = decode(sd, cfg, latent, mask, ids_restore, taps)
     if taps is not None:
         taps["mask"], taps["ids_restore"], taps["pred"] = mask, ids_restore, pred

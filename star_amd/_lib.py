@@ -64,6 +64,12 @@ _SIGS = {
     "star_adamw": (C.c_int, [_P, _P, _P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _I, _P]),
     "star_sumsq": (C.c_int, [_P, _L, _P, _P, _P]),
     "star_iou_confusion": (C.c_int, [_P, _P, _P, _I, _I, _I, _I, _P]),
+    "star_vq_nblocks": (C.c_int, [_I]),
+    "star_vq_assign": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "star_vq_finish": (C.c_int, [_P, _I, _P, _I, _I, _I, _F, _P, _P, _P]),
+    "star_vq_bwd_ws": (C.c_int64, [_I, _I, _I]),
+    "star_vq_bwd": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _I, _P]),
+    "star_onehot_rows": (C.c_int, [_P, _P, _I, _I, _P]),
     "star_voxel_scatter": (C.c_int, [_P, _I, _P, _P, _L, _P, _I, _I, _I, _I, _I, _P, _P]),
 }
 EXPORTS = tuple(_SIGS)

@@ -40,6 +40,9 @@ class Config:
         self.decode_singletemp = model.decode_singletemp
         self.eps = model.blocks[0].norm1.eps
         self.inter = model.compressor[0].out_features
+        vq = getattr(model, "_vq_star", None)                 # VQ-STAR variant (star/models/VQSTAR.py)
+        self.vq = vq is not None
+        self.commitment = float(vq._commitment_cost) if vq is not None else 0.0
         self.grid = self.img // self.patch
         self.L = self.grid * self.grid
         self.V = self.chans * self.patch * self.patch
@@ -185,8 +188,10 @@ def stages(cfg):
         mid.append("mask_token")
     if not cfg.no_temp_emb:
         mid.append("decoder_temp_embed")
-    mid += ["decoder_embed.weight", "decoder_embed.bias", "decompressor.weight", "decompressor.bias",
-            "compressor.0.weight", "compressor.0.bias", "norm.weight", "norm.bias"]
+    mid += ["decoder_embed.weight", "decoder_embed.bias", "decompressor.weight", "decompressor.bias"]
+    if getattr(cfg, "vq", False):
+        mid.append("_vq_star._embedding.weight")
+    mid += ["compressor.0.weight", "compressor.0.bias", "norm.weight", "norm.bias"]
     out.append(mid)
     for i in reversed(range(cfg.depth)):
         out.append(["blocks.%d.%s" % (i, n) for n in blk])
@@ -308,8 +313,17 @@ def forward(cfg, P, W, dt, imgs1, imgs_next, trans_matrices, num_agent, batch, m
     latent_lp, latent, _ = ops.gemm(y, _lin(P, W, "compressor.0", dt), m=n_frames * keep, bias=P["compressor.0.bias"],
                                     act=ACT_RELU, a_rows=comp_rows, want_f32=True)
 
+    # ---- vector quantiser between compressor and decompressor (VQ-STAR only; VQSTAR.py:432,456) -------------------
+    vq = None
+    dec_in_lp = latent_lp
+    if cfg.vq:
+        vq = ops.vq_assign(latent, P["_vq_star._embedding.weight"], dt, want_f32=taps is not None)
+        dec_in_lp = vq["q_lp"]
+        if taps is not None:
+            taps["quantized"], taps["vq_indices"] = vq["q_f32"], vq["idx"]
+
     # ---- decoder ----------------------------------------------------------------------------------------------
-    z, _, _ = ops.gemm(latent_lp, _lin(P, W, "decompressor", dt), bias=P["decompressor.bias"])
+    z, _, _ = ops.gemm(dec_in_lp, _lin(P, W, "decompressor", dt), bias=P["decompressor.bias"])
     dpos = P["decoder_pos_embed"][0, 1:]
     temp = None if cfg.no_temp_emb else P["decoder_temp_embed"].reshape(T, Dd)
     tok = P["mask_token"].reshape(Dd)
@@ -348,12 +362,16 @@ def forward(cfg, P, W, dt, imgs1, imgs_next, trans_matrices, num_agent, batch, m
     if na.dtype not in (torch.int32, torch.int64):
         na = na.long()
     result = ops.warp_fuse(ce["ind8"], theta, na.contiguous(), batch, ego=imgs1 if infer else None, binary=True)
-    out = dict(loss=ce["loss"], result=result, latent=latent.reshape(n_frames, keep, cfg.inter), ind=ce["ind64"])
+    out = dict(loss=ce["loss"], result=result, latent=latent.reshape(n_frames, keep, cfg.inter), ind=ce["ind64"], mask=mask)
+    if cfg.vq:   # loss = vq_loss + recon_loss (VQSTAR.py:443); the sum is formed on the device, in stream order
+        stats = ops.vq_finish(vq["part"], vq["counts"], n_frames * keep, cfg.inter, cfg.commitment, loss_inout=ce["loss"])
+        out.update(vq_loss=stats[0:1], perplexity=stats[1:2], vq_indices=vq["idx"])
     ctx = None
     if train:
         ctx = dict(save=save, a_pe=a_pe, channels_last=channels_last, src_row=src_row, dst_row=dst_row, fill=fill, x_enc=x,
                    mean_e=mean_e, rstd_e=rstd_e, y=y, latent_lp=latent_lp, z=z, xd=xd, mean_d=mean_d, rstd_d=rstd_d, yd=yd,
-                   dlogits=ce["dlogits"], keep=keep, ba=ba, l_enc=l_enc, random_mode=random_mode)
+                   dlogits=ce["dlogits"], keep=keep, ba=ba, l_enc=l_enc, random_mode=random_mode, dec_in_lp=dec_in_lp,
+                   latent=latent if cfg.vq else None, vq_idx=vq["idx"] if cfg.vq else None)
     return out, ctx
 
 
@@ -408,8 +426,16 @@ def backward(cfg, P, W, dt, ctx, G=None, on_ready=None):
         _put(grads, G, "decoder_temp_embed", gt.reshape(1, T, 1, Dd))
     _wg(grads, G, "decoder_embed", dye, ctx["z"])
     dz, _, _ = ops.gemm(dye, _lin(P, W, "decoder_embed", dt, True))
-    _wg(grads, G, "decompressor", dz, ctx["latent_lp"])
-    dlat, _, _ = ops.gemm(dz, _lin(P, W, "decompressor", dt, True), act=ACT_DRELU, aux=ctx["latent_lp"])
+    _wg(grads, G, "decompressor", dz, ctx["dec_in_lp"])
+    if cfg.vq:
+        # straight-through estimator: the decoder's gradient passes to the latent, plus the commitment term; the codebook
+        # only sees the q_latent term (mae_base.py:162-166); then the compressor's ReLU
+        dq, _, _ = ops.gemm(dz, _lin(P, W, "decompressor", dt, True))
+        name = "_vq_star._embedding.weight"
+        dlat, dcb = ops.vq_bwd(dq, ctx["latent"], ctx["vq_idx"], P[name], cfg.commitment, dcodebook=None if G is None else G[name])
+        grads[name] = dcb
+    else:
+        dlat, _, _ = ops.gemm(dz, _lin(P, W, "decompressor", dt, True), act=ACT_DRELU, aux=ctx["latent_lp"])
     comp_rows = None if cfg.encode_partial else ctx["src_row"]
     _wg(grads, G, "compressor.0", dlat, ctx["y"], x_rows=comp_rows)
     rows_enc = n_frames * ctx["l_enc"]

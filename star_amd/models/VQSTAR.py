@@ -1,0 +1,66 @@
+"""VQ-STAR: the STAR completion model with a vector quantiser between compressor and decompressor.
+
+Mirrors the reference interface star/models/VQSTAR.py:14-480 (`VQSTARViT`, constructor arguments, `forward` /
+`inference` signatures and return tuples, factory `vq_amo_individual_star_patch8_dec256d4b` and its alias `vqstar`
+that completion/train_completion.py:93-98 calls) and the state-dict key `_vq_star._embedding.weight` of
+STARVectorQuantizer (star/models/mae_base.py:107-120).  Everything else of the model is the amortised-individual
+path (the reference's VQSTAR.py repeats those methods verbatim); the quantiser runs in libstar_hip.so
+(star_vq_assign / star_vq_finish / star_vq_bwd)."""
+from functools import partial
+
+import torch.nn as nn
+
+from .. import ops
+from .multiagent_mae import AmortizedIndivMMAEViT
+
+
+class STARVectorQuantizer(nn.Module):
+    """Parameter holder with the reference's names: codebook `_embedding.weight` [K, E] ~ N(0, 1) (nn.Embedding's
+    default; the reference leaves it untouched -- it is created after initialize_weights ran)."""
+
+    def __init__(self, num_embeddings, embedding_dim, commitment_cost):
+        super().__init__()
+        self._embedding_dim = embedding_dim
+        self._num_embeddings = num_embeddings
+        self._embedding = nn.Embedding(num_embeddings, embedding_dim)
+        self._commitment_cost = commitment_cost
+        self.data_initialized = 1            # mae_base.py:120: the k-means re-initialisation never triggers
+
+
+class VQSTARViT(AmortizedIndivMMAEViT):
+    def __init__(self, img_size=224, patch_size=16, in_chans=3, embed_dim=1024, depth=24, num_heads=16, decoder_embed_dim=512,
+                 decoder_depth=8, decoder_num_heads=16, mlp_ratio=4., norm_layer=nn.LayerNorm, decoder_head="mlp", norm_pix_loss=False,
+                 time_stamp=1, mask_method="complement", encode_partial=False, no_temp_emb=False, decode_singletemp=False, decay=0.,
+                 commitment_cost=0.25, num_vq_embeddings=512, vq_embedding_dim=64):
+        super().__init__(img_size=img_size, patch_size=patch_size, in_chans=in_chans, embed_dim=embed_dim, depth=depth,
+                         num_heads=num_heads, decoder_embed_dim=decoder_embed_dim, decoder_depth=decoder_depth,
+                         decoder_num_heads=decoder_num_heads, mlp_ratio=mlp_ratio, norm_layer=norm_layer, decoder_head=decoder_head,
+                         norm_pix_loss=norm_pix_loss, time_stamp=time_stamp, mask_method=mask_method, encode_partial=encode_partial,
+                         no_temp_emb=no_temp_emb, decode_singletemp=decode_singletemp, inter_emb_dim=vq_embedding_dim)
+        if decay > 0.0:
+            # STARVectorQuantizerEMA (mae_base.py:176-253) replaces its parameters inside forward; the CLI default is 0
+            raise NotImplementedError("VQ-STAR with an EMA codebook (decay > 0) is outside the accelerated path; use decay=0")
+        if vq_embedding_dim not in (8, 16, 32, 64, 128):
+            raise NotImplementedError("vq_embedding_dim must be one of 8, 16, 32, 64, 128 (got %d)" % vq_embedding_dim)
+        self._vq_star = STARVectorQuantizer(num_vq_embeddings, vq_embedding_dim, commitment_cost)
+
+    def forward(self, imgs1, imgs_next, teacher, trans_matrices, num_agent_tensor, batch_size, mask_ratio=0.75):
+        """-> (loss = vq + reconstruction, result, mask, ind_result, perplexity)   (VQSTAR.py:421-444)"""
+        loss, result, _latent, ind, mask, perplexity, _ = self._run(
+            self._inputs(imgs1, imgs_next, trans_matrices, num_agent_tensor, batch_size, mask_ratio, infer=False))
+        return loss, result, mask, ind, perplexity.reshape(())
+
+    def inference(self, imgs1, imgs_next, teacher, trans_matrices, num_agent_tensor, batch_size, mask_ratio=0.75):
+        """-> (loss, result, ind_result, perplexity, encodings [rows, K] one-hot)   (VQSTAR.py:446-470)"""
+        loss, result, _latent, ind, _mask, perplexity, vq_idx = self._run(
+            self._inputs(imgs1, imgs_next, trans_matrices, num_agent_tensor, batch_size, mask_ratio, infer=True))
+        return loss, result, ind, perplexity.reshape(()), ops.onehot_rows(vq_idx, self._vq_star._num_embeddings)
+
+
+def vq_amo_individual_star_patch8_dec256d4b(**kwargs):
+    return VQSTARViT(img_size=kwargs.pop("img_size", 256), patch_size=8, in_chans=13, embed_dim=384, depth=6, num_heads=12,
+                     decoder_embed_dim=256, decoder_depth=4, decoder_num_heads=16, mlp_ratio=4, norm_layer=partial(nn.LayerNorm, eps=1e-6),
+                     decoder_head="mlp", **kwargs)
+
+
+vqstar = vq_amo_individual_star_patch8_dec256d4b

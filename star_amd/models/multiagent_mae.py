@@ -17,6 +17,9 @@ from .._lib import BF16, F32
 from .mae_base import MultiAgentMaskedAutoencoderViT
 
 
+_EXTRAS = ("mask", "perplexity", "vq_indices")     # after (loss, result, latent, ind): what the VQ-STAR variant also returns
+
+
 class _StarFunction(torch.autograd.Function):
     """One autograd node for the whole model: forward runs the HIP forward chain and keeps the
     activations, backward runs the HIP backward chain and hands one gradient per parameter."""
@@ -27,8 +30,9 @@ class _StarFunction(torch.autograd.Function):
         P.update(model._frozen_tables())
         out, saved = engine.forward(model._cfg(), P, model._weights, model._dt(), train=True, **inputs)
         ctx.model, ctx.names, ctx.saved, ctx.P = model, names, saved, P
-        ctx.mark_non_differentiable(out["result"], out["latent"], out["ind"])
-        return out["loss"].reshape(()), out["result"], out["latent"], out["ind"]
+        extras = tuple(out[k] for k in _EXTRAS if k in out)
+        ctx.mark_non_differentiable(out["result"], out["latent"], out["ind"], *extras)
+        return (out["loss"].reshape(()), out["result"], out["latent"], out["ind"]) + extras
 
     @staticmethod
     def backward(ctx, gloss, *_unused):
@@ -54,11 +58,12 @@ class AmortizedIndivMMAEViT(MultiAgentMaskedAutoencoderViT):
     def __init__(self, img_size=224, patch_size=16, in_chans=3, embed_dim=1024, depth=24, num_heads=16,
                  decoder_embed_dim=512, decoder_depth=8, decoder_num_heads=16, mlp_ratio=4., norm_layer=nn.LayerNorm,
                  decoder_head="mlp", norm_pix_loss=False, time_stamp=1, mask_method="random", encode_partial=False,
-                 no_temp_emb=False, decode_singletemp=False):
+                 no_temp_emb=False, decode_singletemp=False, inter_emb_dim=32):
         super().__init__(img_size=img_size, patch_size=patch_size, in_chans=in_chans, embed_dim=embed_dim, depth=depth,
                          num_heads=num_heads, decoder_embed_dim=decoder_embed_dim, decoder_depth=decoder_depth,
                          decoder_num_heads=decoder_num_heads, mlp_ratio=mlp_ratio, norm_layer=norm_layer,
-                         decoder_head=decoder_head, norm_pix_loss=norm_pix_loss, time_stamp=time_stamp, mask_method=mask_method)
+                         decoder_head=decoder_head, norm_pix_loss=norm_pix_loss, time_stamp=time_stamp, mask_method=mask_method,
+                         inter_emb_dim=inter_emb_dim)
         self.patch_h = 0
         self.patch_w = 0
         if mask_method not in ("random", "complement"):
@@ -120,18 +125,18 @@ class AmortizedIndivMMAEViT(MultiAgentMaskedAutoencoderViT):
             return _StarFunction.apply(self, inputs, names, *params)
         P = {n: prm for n, prm in self.named_parameters()}
         out, _ = engine.forward(self._cfg(), P, self._weights, self._dt(), train=False, **inputs)
-        return out["loss"].reshape(()), out["result"], out["latent"], out["ind"]
+        return (out["loss"].reshape(()), out["result"], out["latent"], out["ind"]) + tuple(out[k] for k in _EXTRAS if k in out)
 
     # ---- reference interface ----------------------------------------------------------------------------
     def forward(self, imgs1, imgs_next, teacher, trans_matrices, num_agent_tensor, batch_size, mask_ratio=0.75):
         """-> (loss, result [A*B,C,H,W] float32 in {0,1}, latent [A*B*T, keep, 32], ind_result int64).
         The loss target is the agent's own input, `teacher` is unused (reference Q4); the ego slot of the fusion
         uses the agent's own prediction (late_fusion)."""
-        return self._run(self._inputs(imgs1, imgs_next, trans_matrices, num_agent_tensor, batch_size, mask_ratio, infer=False))
+        return self._run(self._inputs(imgs1, imgs_next, trans_matrices, num_agent_tensor, batch_size, mask_ratio, infer=False))[:4]
 
     def inference(self, imgs1, imgs_next, teacher, trans_matrices, num_agent_tensor, batch_size, mask_ratio=0.75):
         """Same tuple; the ego slot of the fusion uses the agent's own INPUT (ego_late_fusion)."""
-        return self._run(self._inputs(imgs1, imgs_next, trans_matrices, num_agent_tensor, batch_size, mask_ratio, infer=True))
+        return self._run(self._inputs(imgs1, imgs_next, trans_matrices, num_agent_tensor, batch_size, mask_ratio, infer=True))[:4]
 
 
 # ---- factory functions (multiagent_mae.py:1129-1184) -------------------------------------------------------

@@ -397,3 +397,52 @@ def voxel_scatter(idx, offsets, dims, channels_first=False, validate=True, out=N
     if validate and int(err.item()) != 0:
         raise IndexError("voxel index out of bounds for dims %r" % (tuple(dims),))
     return out
+
+
+# ---- VQ-STAR quantiser -----------------------------------------------------------------------------------
+def vq_assign(x, codebook, dt, want_f32=True, want_lp=True, want_stats=True):
+    """x float32 [M,E], codebook float32 [K,E] -> dict(idx int64 [M], q_f32, q_lp, part, counts)."""
+    _cuda(x, codebook)
+    assert x.dtype == torch.float32 and codebook.dtype == torch.float32 and x.is_contiguous() and codebook.is_contiguous()
+    m, e = x.shape
+    k = codebook.shape[0]
+    assert codebook.shape[1] == e
+    dev = x.device
+    idx = torch.empty(m, dtype=torch.int64, device=dev)
+    q32 = torch.empty(m, e, dtype=torch.float32, device=dev) if want_f32 else None
+    qlp = torch.empty(m, e, dtype=L.torch_dtype(dt), device=dev) if want_lp else None
+    nb = L.lib().star_vq_nblocks(m)
+    part = torch.empty(nb, dtype=torch.float32, device=dev) if want_stats else None
+    counts = torch.empty(k, dtype=torch.int32, device=dev) if want_stats else None
+    with _timed("vq_assign", 2.0 * m * k * e, float(m * e * 4 + k * e * 4 + m * 8)):
+        L.check(L.lib().star_vq_assign(p(x), p(codebook), p(idx), p(q32), p(qlp), p(part), p(counts), m, e, k, dt, L.stream()))
+    return dict(idx=idx, q_f32=q32, q_lp=qlp, part=part, counts=counts)
+
+
+def vq_finish(part, counts, m, e, commitment, loss_inout=None):
+    """-> float32 [3] = (vq loss, perplexity, mse); loss_inout[0] += vq loss."""
+    out = torch.empty(3, dtype=torch.float32, device=part.device)
+    L.check(L.lib().star_vq_finish(p(part), part.numel(), p(counts), m, e, counts.numel(), float(commitment), p(out), p(loss_inout), L.stream()))
+    return out
+
+
+def vq_bwd(dq, x, idx, codebook, commitment, want_dlat=True, dcodebook=None, want_dcodebook=True):
+    """-> (dlat in dq's dtype [M,E], dcodebook float32 [K,E])."""
+    m, e = x.shape
+    k = codebook.shape[0]
+    dt = L.dt_of(dq)
+    assert dq.is_contiguous() and tuple(dq.shape) == (m, e)
+    dlat = torch.empty_like(dq) if want_dlat else None
+    if dcodebook is None and want_dcodebook:
+        dcodebook = torch.empty(k, e, dtype=torch.float32, device=x.device)
+    assert dcodebook is None or (dcodebook.is_contiguous() and dcodebook.numel() == k * e and dcodebook.dtype == torch.float32)
+    ws = torch.empty(L.lib().star_vq_bwd_ws(m, e, k), dtype=torch.float32, device=x.device) if dcodebook is not None else None
+    with _timed("vq_bwd", 0.0, float(m * e * (4 + 2 * dq.element_size()) + 2 * k * e * 4)):
+        L.check(L.lib().star_vq_bwd(p(dq), p(x), p(idx), p(codebook), p(dlat), p(dcodebook), p(ws), m, e, k, float(commitment), dt, L.stream()))
+    return dlat, dcodebook
+
+
+def onehot_rows(idx, k):
+    out = torch.empty(idx.numel(), k, dtype=torch.float32, device=idx.device)
+    L.check(L.lib().star_onehot_rows(p(idx), p(out), idx.numel(), k, L.stream()))
+    return out

@@ -30,7 +30,12 @@ def add_weight_decay(model, weight_decay=1e-5, skip_list=()):
 class FlatAdamW:
     is_star_flat = True
 
-    def __init__(self, model, lr=1e-3, betas=(0.9, 0.95), eps=1e-8, weight_decay=0.05):
+    def __init__(self, model, lr=1e-3, betas=(0.9, 0.95), eps=1e-8, weight_decay=0.05, grouping="timm"):
+        """grouping: layout of state_dict()'s param groups -- "timm" = add_weight_decay's two groups (the ind_mae
+        optimizer, train_completion.py:124-125), "flat" = one group over model.parameters() (the vqstar optimizer,
+        optim.Adam(model.parameters()) at train_completion.py:128; use weight_decay=0 with it)."""
+        assert grouping in ("timm", "flat"), grouping
+        self.grouping = grouping
         self.model = model
         cfg = model._cfg()
         named = dict(model.named_parameters())
@@ -85,11 +90,17 @@ class FlatAdamW:
         """L2 norm of the (unscaled) gradient, as the reference's get_grad_norm_ reads it; a device scalar."""
         return ops.sumsq(self.flat_g).sqrt()
 
+    def _groups(self):
+        wd = self.param_groups[0]["weight_decay"]
+        if self.grouping == "flat":
+            return [{"params": list(self.model.parameters()), "weight_decay": wd}]
+        return add_weight_decay(self.model, wd)
+
     def state_dict(self):
         """torch.optim.AdamW layout over timm's two groups (no-decay first), so checkpoints interchange with
         the reference's `optimizer_state_dict`."""
-        order = add_weight_decay(self.model, self.param_groups[0]["weight_decay"])
-        ids = {id(p): i for i, p in enumerate(order[0]["params"] + order[1]["params"])}
+        order = self._groups()
+        ids = {id(p): i for i, p in enumerate([p for grp in order for p in grp["params"]])}
         named = dict(self.model.named_parameters())
         state = {}
         if self.step_count > 0:
@@ -107,8 +118,7 @@ class FlatAdamW:
         return dict(state=state, param_groups=groups)
 
     def load_state_dict(self, sd):
-        order = add_weight_decay(self.model, self.param_groups[0]["weight_decay"])
-        plist = order[0]["params"] + order[1]["params"]
+        plist = [p for grp in self._groups() for p in grp["params"]]
         names = {id(p): n for n, p in self.model.named_parameters()}
         for idx, st in sd["state"].items():
             n = names[id(plist[int(idx)])]

@@ -19,8 +19,8 @@ class CoModule(object):
         self.optimizer = optimizer
         self.parallel = parallel
         self.scheduler = None            # only the 'late' / 'vqvae' baselines of the reference use one
-        if com not in ("ind_mae", "joint_mae"):
-            raise NotImplementedError("star_amd accelerates the 'ind_mae' completion path; com=%r is out of scope" % (com,))
+        if com not in ("ind_mae", "joint_mae", "vqstar"):
+            raise NotImplementedError("star_amd accelerates the 'ind_mae' and 'vqstar' completion paths; com=%r is out of scope" % (com,))
 
     def resume_from_cpu(self, checkpoint, device, trainable=True):
         """Load a (reference-format) checkpoint that was read with map_location='cpu', then move to `device`."""
@@ -43,10 +43,8 @@ class CoModule(object):
         bev_teacher = data['bev_seq_teacher'].squeeze(1).permute(0, 3, 1, 2)
         return bev_seq, bev_seq_next, bev_teacher, data['trans_matrices'], data['num_agent']
 
-    def step_mae_completion(self, data, batch_size, mask_ratio, loss_fn='mse', trainable=False):
-        bev_seq, bev_seq_next, bev_teacher, trans_matrices, num_agent_tensor = self._unpack(data)
-        loss, result, _, ind_pred = self.model(bev_seq, bev_seq_next, bev_teacher, trans_matrices, num_agent_tensor,
-                                               batch_size, mask_ratio=mask_ratio)
+    def _step(self, loss, trainable):
+        """Loss readback, finite check and parameter update shared by the mae and vqstar steps."""
         fused = trainable and getattr(self.optimizer, "is_star_flat", False)
         if fused:
             # enqueue the whole backward (and the bucketed gradient all-reduce) BEFORE the host reads the loss,
@@ -63,7 +61,28 @@ class CoModule(object):
         elif trainable:
             self.mae_loss_scaler(loss, self.optimizer, parameters=self.model.parameters(), update_grad=True)
             self.optimizer.zero_grad()
-        return loss_value, result, ind_pred.detach()
+        return loss_value
+
+    def step_mae_completion(self, data, batch_size, mask_ratio, loss_fn='mse', trainable=False):
+        bev_seq, bev_seq_next, bev_teacher, trans_matrices, num_agent_tensor = self._unpack(data)
+        loss, result, _, ind_pred = self.model(bev_seq, bev_seq_next, bev_teacher, trans_matrices, num_agent_tensor,
+                                               batch_size, mask_ratio=mask_ratio)
+        return self._step(loss, trainable), result, ind_pred.detach()
+
+    def step_vqstar_completion(self, data, batch_size, mask_ratio, loss_fn='mse', trainable=False):
+        """star/utils/CoModule.py:193-229 -> (loss, result, ind_pred, perplexity)."""
+        bev_seq, bev_seq_next, bev_teacher, trans_matrices, num_agent_tensor = self._unpack(data)
+        loss, result, _, ind_pred, perplexity = self.model(bev_seq, bev_seq_next, bev_teacher, trans_matrices, num_agent_tensor,
+                                                           batch_size, mask_ratio=mask_ratio)
+        return self._step(loss, trainable), result, ind_pred.detach(), perplexity.detach()
+
+    def infer_vqstar_completion(self, data, batch_size, mask_ratio, loss_fn='mse'):
+        """star/utils/CoModule.py:231-253 -> (loss, result, ind_pred, perplexity, encodings)."""
+        bev_seq, bev_seq_next, bev_teacher, trans_matrices, num_agent_tensor = self._unpack(data)
+        with torch.no_grad():
+            loss, result, ind_pred, perplexity, encodings = self.model.inference(bev_seq, bev_seq_next, bev_teacher, trans_matrices,
+                                                                                 num_agent_tensor, batch_size, mask_ratio=mask_ratio)
+        return loss.item(), result, ind_pred.detach(), perplexity.detach(), encodings.detach()
 
     def infer_mae_completion(self, data, batch_size, mask_ratio, loss_fn='mse'):
         bev_seq, bev_seq_next, bev_teacher, trans_matrices, num_agent_tensor = self._unpack(data)

@@ -118,9 +118,33 @@ def voxel_cases():
     return rows
 
 
+def vq_cases():
+    rows = []
+    g = torch.Generator().manual_seed(0)
+    for K, E in ((8192, 32), (512, 64)):
+        x = torch.relu(torch.randn(M, E, generator=g)).to(dev)
+        cb = (torch.randn(K, E, generator=g) * 0.5).abs().to(dev)
+        v = ops.vq_assign(x, cb, 0)
+        us = timeit(lambda: ops.vq_assign(x, cb, 0))
+        rows.append(("vq assign", K, E, us, 2.0 * M * K * E / us / 1e6, (M * E * 10 + K * E * 4) / us / 1e3))
+        dq = torch.randn(M, E, generator=g).to(dev).bfloat16()
+        us = timeit(lambda: ops.vq_bwd(dq, x, v["idx"], cb, 0.25))
+        rows.append(("vq bwd", K, E, us, 0.0, (M * E * 8 + K * E * 8) / us / 1e3))
+        # collapsed codebook: every row picks code 0 (what early VQ-STAR training looks like)
+        cb2 = cb + 100.0
+        cb2[0] = x.mean(0)
+        v2 = ops.vq_assign(x, cb2, 0)
+        assert int(v2["counts"].max()) == M
+        us = timeit(lambda: ops.vq_assign(x, cb2, 0))
+        rows.append(("vq assign 1code", K, E, us, 2.0 * M * K * E / us / 1e6, 0.0))
+        us = timeit(lambda: ops.vq_bwd(dq, x, v2["idx"], cb2, 0.25))
+        rows.append(("vq bwd 1code", K, E, us, 0.0, 0.0))
+    return rows
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["gemm", "wgrad", "attn", "ln", "voxel"]
+    which = sys.argv[1:] or ["gemm", "wgrad", "attn", "ln", "voxel", "vq"]
     for w in which:
-        rows = dict(gemm=gemm_cases, wgrad=wgrad_cases, attn=attn_cases, ln=ln_cases, voxel=voxel_cases)[w]()
+        rows = dict(gemm=gemm_cases, wgrad=wgrad_cases, attn=attn_cases, ln=ln_cases, voxel=voxel_cases, vq=vq_cases)[w]()
         for name, a, b, us, tf, gbs in rows:
             print("%-14s %5d %5d  %8.1f us  %7.1f TFLOP/s  %7.1f GB/s(or Gexp/s)" % (name, a, b, us, tf, gbs))
