@@ -101,15 +101,24 @@ def cpu_baseline(args, cores):
 
 def main():
     args = parse()
+    if os.environ.get("STAR_AMD_WATCHDOG"):     # debugging aid: dump every thread's stack and exit if the run takes longer
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ["STAR_AMD_WATCHDOG"]), exit=True)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
+        torch.cuda.set_device(local % torch.cuda.device_count())
+        backend = os.environ.get("STAR_AMD_DIST_BACKEND", "nccl")   # "gloo": rehearsal of the N>1 flow where RCCL cannot run (ranks sharing one GPU)
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend=backend)
     assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)" % (args.gpus, world)
+    if local >= torch.cuda.device_count():      # rehearsal on a box with fewer GPUs than ranks
+        local = local % torch.cuda.device_count()
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
 

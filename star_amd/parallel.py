@@ -13,7 +13,12 @@ import torch.distributed as dist
 
 
 class SceneParallel:
-    def __init__(self, model, optimizer, process_group=None, bucket_mb=8.0):
+    def __init__(self, model, optimizer, process_group=None, bucket_mb=8.0, overlap=None, force=False):
+        """overlap: launch each bucket's all-reduce from the backward chain as soon as its gradients are enqueued
+        (default for RCCL, where the collective is stream-ordered); False = launch all buckets in finish().  The gloo
+        rehearsal defaults to False: its GPU path stages through pinned host buffers allocated inside the call, which
+        was seen to dead-lock against the kernel-launching backward thread when two ranks share one GPU.
+        force: install the hooks even with one rank (tests of the RCCL call path on a single GPU)."""
         if not getattr(optimizer, "is_star_flat", False):
             raise TypeError("SceneParallel reduces the flat gradient buffer of star_amd.optim.FlatAdamW")
         self.model, self.opt, self.group = model, optimizer, process_group
@@ -31,24 +36,36 @@ class SceneParallel:
         self.pending = []
         # RCCL averages in the collective; gloo (CPU rehearsal of the same logic) sums and divides afterwards
         self.native_avg = dist.is_initialized() and dist.get_backend(process_group) == "nccl"
-        model._on_grads_ready = self._ready if self.world > 1 else None
+        self.overlap = self.native_avg if overlap is None else bool(overlap)
+        self.deferred = []
+        self.active = self.world > 1 or (force and dist.is_initialized())
+        model._on_grads_ready = self._ready if self.active else None
 
     def broadcast_parameters(self, src=0):
-        if self.world > 1:
+        if self.active:
             dist.broadcast(self.opt.flat_p, src, group=self.group)
             for name, buf in self.model.named_buffers():
                 dist.broadcast(buf, src, group=self.group)
             self.model._weights.epoch += 1
 
+    def _launch(self, rng):
+        view = self.opt.flat_g[rng[0]:rng[1]]
+        op = dist.ReduceOp.AVG if self.native_avg else dist.ReduceOp.SUM
+        self.pending.append((dist.all_reduce(view, op=op, group=self.group, async_op=True), view))
+
     def _ready(self, stage):
         rng = self.close_at.get(stage)
         if rng is not None:
-            view = self.opt.flat_g[rng[0]:rng[1]]
-            op = dist.ReduceOp.AVG if self.native_avg else dist.ReduceOp.SUM
-            self.pending.append((dist.all_reduce(view, op=op, group=self.group, async_op=True), view))
+            if self.overlap:
+                self._launch(rng)
+            else:
+                self.deferred.append(rng)
 
     def finish(self):
         """Make the compute stream wait for every outstanding bucket (call between backward and step)."""
+        for rng in self.deferred:
+            self._launch(rng)
+        self.deferred = []
         for work, view in self.pending:
             work.wait()
             if not self.native_avg:

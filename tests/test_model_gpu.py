@@ -147,3 +147,44 @@ def test_cpu_input_is_rejected_loudly():
     m = build(c, "bf16")
     with pytest.raises(RuntimeError, match="MI355X"):
         m.inference(c.bev, c.next, c.teacher, torch.from_numpy(c.trans), torch.from_numpy(c.num_agent), c.B)
+
+
+def test_scene_parallel_rccl_call_path_single_rank():
+    """The bucketed, backward-overlapped gradient all-reduce on the real RCCL backend with ONE rank (all a single-GPU box
+    can host): AVG over one rank is the identity, so parameters after two fused steps must equal the run without it,
+    bit for bit -- while every collective call (views of the flat buffer, async launch from the backward thread,
+    stream-ordered wait, broadcast) goes through RCCL."""
+    import os
+
+    import torch.distributed as dist
+
+    from star_amd.optim import FlatAdamW
+    from star_amd.parallel import SceneParallel
+    from star_amd.synthetic import make_batch
+    from star_amd.utils.CoModule import CoModule
+
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        outs = []
+        for use_par in (False, True):
+            torch.manual_seed(0)
+            d = dict(patch_size=8, in_chans=13, embed_dim=64, depth=2, num_heads=2, decoder_embed_dim=64, decoder_depth=1, decoder_num_heads=4,
+                     mlp_ratio=4, norm_layer=partial(nn.LayerNorm, eps=1e-6))
+            model = AmortizedIndivMMAEViT(img_size=64, time_stamp=2, mask_method="complement", **d).to(DEV)
+            opt = FlatAdamW(model, lr=1e-3, betas=(0.9, 0.95), weight_decay=0.05)
+            par = SceneParallel(model, opt, bucket_mb=0.05, force=True) if use_par else None
+            if par is not None:
+                assert par.native_avg and par.overlap and len(par.close_at) > 1
+                par.broadcast_parameters(0)
+            cm = CoModule(model, opt, "ind_mae", parallel=par)
+            data = make_batch(2, 3, 2, 64, seed=5, occupancy=0.1, device=DEV)
+            for it in range(2):
+                torch.manual_seed(50 + it)
+                loss, _, _ = cm.step_mae_completion(data, 2, 0.75, trainable=True)
+            outs.append((loss, opt.flat_p.detach().clone()))
+            assert par is None or len(par.pending) == 0
+        assert outs[0][0] == outs[1][0] and torch.equal(outs[0][1], outs[1][1])
+    finally:
+        dist.destroy_process_group()
