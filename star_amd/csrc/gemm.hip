@@ -290,33 +290,59 @@ __device__ __forceinline__ int ntf_swz(int row) { return (0x78 >> (((row >> 2) &
 #define EPI_RES 2       // bias + one float32 residual table; no activation
 #define EPI_GELU_GRAD 3 // bias + GELU, `pre` receives gelu' (STAR_GEMM_PRE_IS_GRAD)
 #define EPI_MULAUX 4    // times aux; no bias, no residual
-template <int NST, int EPI>
-__global__ __launch_bounds__(GT) __attribute__((amdgpu_waves_per_eu(3))) void gemm_nt_fast_kernel(const StarGemm g) {
-    constexpr int BM = 128, BN = 128, STAGE = (BM + BN) * 64, PF = NST - 1;
+// Tile geometry: WM x WN waves, each wave RB 16-row blocks (rows) x 64 columns.
+//   <2,2,4>: 128 x 128, 4 waves (3 blocks per CU)   -- narrow outputs (N <= 256) and small problems
+//   <4,2,4>: 256 x 128, 8 waves (2 blocks per CU)   -- N = 384: a 128-wide W panel per tile, 25 % fewer operand bytes per flop
+//   <2,4,8>: 256 x 256, 8 waves (1 block per CU)    -- wide outputs: half the operand bytes per flop
+// What bounds the 128 x 128 tile at K = 256..384 is the rate at which a CU takes operand bytes in through LDS-DMA
+// (measured: 12 waves spend 55 % of their cycles issue-stalled, MFMA pipe 24 % busy): every tile re-reads a full
+// 98 KB W panel and A panel for 12.6 MFLOP.  Bigger tiles cut that ratio; the per-wave code is the same.
+// Column groups (CG): which 16 output columns of its wave's 64-column block a lane owns.  Accumulator block a, register j of
+// lane group lg is LDS row a*16 + lg*4 + j of the W image; the image holds W row perm(row), so that a lane's four
+// 4-column runs land where a 16-byte store per lane makes every ROW's four lanes write one contiguous 64-byte segment:
+//   CG = 8 (a bf16 output exists): run a -> columns (a>>1)*32 + lg*8 + (a&1)*4 : lanes lg = 0..3 x 16 B of bf16 = 32 columns
+//   CG = 4 (float32 outputs only): run a -> columns a*16 + lg*4                 : lanes lg = 0..3 x 16 B of f32  = 16 columns
+// (16 contiguous columns per lane -- the earlier layout -- made each store instruction write 16-byte pieces 32 or 64
+// bytes apart: four times the write requests for the same bytes.)
+template <int CG> __device__ __forceinline__ int ntf_run_off(int lg, int a) {
+    return CG == 8 ? ((a >> 1) * 32 + lg * 8 + (a & 1) * 4) : (a * 16 + lg * 4);
+}
+template <int NST, int EPI, int WM, int WN, int RB, int CG>
+__global__ __launch_bounds__(WM * WN * 64) __attribute__((amdgpu_waves_per_eu(WM * WN == 4 ? 3 : (RB == 8 ? 2 : 4))))
+void gemm_nt_fast_kernel(const StarGemm g) {
+    static_assert(CG == 4 || CG == 8, "column groups of 4 (float32 outputs) or 8 (bf16 outputs)");
+    constexpr int NW = WM * WN, BM = WM * RB * 16, BN = WN * 64, STAGE = (BM + BN) * 64, PF = NST - 1;
+    constexpr int NA = BM / 16 / NW, NWP = BN / 16 / NW, NDMA = NA + NWP;   // LDS-DMA pieces (16 rows x 64 B) per wave and stage
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int M = g.M, N = g.N, K = g.K;
     const int tiles_n = (N + BN - 1) / BN, tiles_m = (M + BM - 1) / BM, ntiles = tiles_m * tiles_n;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave & 1, wn = wave >> 1;
+    const int wm = wave % WM, wn = wave / WM;
     const int lr = lane & 15, lg = lane >> 4;
 
     // ---- LDS-DMA addressing: a wave instruction fills 16 rows x 64 B = 1 KiB; this wave owns rows wave*32..+31
     __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g.A), 0, 0x7fffffff, 0x00020000);
     __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g.W), 0, 0x7fffffff, 0x00020000);
-    unsigned offA[2], offW[2];
+    unsigned offA[2], offW[2];   // NA, NWP <= 2 (fixed bounds: a dependent bound here makes hipcc drop the kernel on the host side)
+    static_assert(NA <= 2 && NWP <= 2, "LDS-DMA offset tables hold two pieces");
     auto dma_setup = [&](int m_blk, int n_blk) {
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int r = wave * 32 + j * 16 + (lane >> 2);
+        for (int j = 0; j < NA; ++j) {
+            const int r = (wave * NA + j) * 16 + (lane >> 2);
             const int c = (lane & 3) ^ ntf_swz(r);
-            // the W image holds row pi(r) at LDS row r, pi = swap of the bit fields [5:4] and [3:2]: MFMA block a,
-            // accumulator register j of lane group lg then is output column lg*16 + a*4 + j -- 16 CONTIGUOUS columns
-            // per lane, so the epilogue stores whole 32/64-byte runs straight from the registers (no LDS staging)
-            const int m = m_blk + r, n = n_blk + ((r & ~63) | ((r & 0x0c) << 2) | ((r & 0x30) >> 2) | (r & 3));
+            const int m = m_blk + r;
             long long src = -1;
             if (m < M) src = g.a_rows ? (long long)g.a_rows[m] : (long long)m;
             offA[j] = src >= 0 ? (unsigned)(src * K * 2 + c * 16) : 0x7fffffffu;
+        }
+#pragma unroll
+        for (int j = 0; j < NWP; ++j) {
+            const int r = (wave * NWP + j) * 16 + (lane >> 2);
+            const int c = (lane & 3) ^ ntf_swz(r);
+            // LDS row r = a*16 + lg*4 + j (within its 64-row block) holds W row = the output column of accumulator
+            // (a, lg, j): see ntf_run_off
+            const int n = n_blk + (r & ~63) + ntf_run_off<CG>((r >> 2) & 3, (r >> 4) & 3) + (r & 3);
             offW[j] = n < N ? (unsigned)((long long)n * K * 2 + c * 16) : 0x7fffffffu;
         }
     };
@@ -324,20 +350,25 @@ __global__ __launch_bounds__(GT) __attribute__((amdgpu_waves_per_eu(3))) void ge
         unsigned char* st = smem + (kt % NST) * STAGE;
         const unsigned kb = kt * (NTF_BK * 2);
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (__attribute__((address_space(3))) void*)(st + (wave * 32 + j * 16) * 64), 16,
+        for (int j = 0; j < NA; ++j)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (__attribute__((address_space(3))) void*)(st + (wave * NA + j) * 16 * 64), 16,
                                                      offA[j] + kb, 0, 0, 0);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (__attribute__((address_space(3))) void*)(st + BM * 64 + (wave * 32 + j * 16) * 64), 16,
+#pragma unroll
+        for (int j = 0; j < NWP; ++j)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (__attribute__((address_space(3))) void*)(st + BM * 64 + (wave * NWP + j) * 16 * 64), 16,
                                                      offW[j] + kb, 0, 0, 0);
-        }
     };
     // fragment addresses inside a stage (constant over k-steps and tiles)
-    int fw[4], fx[4];
+    int fw[4], fx[RB];
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
-        const int rw_ = wn * 64 + a * 16 + lr, rx_ = wm * 64 + a * 16 + lr;
+        const int rw_ = wn * 64 + a * 16 + lr;
         fw[a] = BM * 64 + rw_ * 64 + ((lg ^ ntf_swz(rw_)) << 4);
-        fx[a] = rx_ * 64 + ((lg ^ ntf_swz(rx_)) << 4);
+    }
+#pragma unroll
+    for (int b = 0; b < RB; ++b) {
+        const int rx_ = wm * (RB * 16) + b * 16 + lr;
+        fx[b] = rx_ * 64 + ((lg ^ ntf_swz(rx_)) << 4);
     }
     // epilogue constants
     bf16_t* out_lp = (bf16_t*)g.out_lp;
@@ -370,18 +401,22 @@ __global__ __launch_bounds__(GT) __attribute__((amdgpu_waves_per_eu(3))) void ge
     while (true) {
         // ---- epilogue set-up, done BEFORE the main loop so that its global reads (row indices, the first two row
         // groups of the residual / aux operand) are in flight under the MFMA work.  Lane (lr, lg) owns rows
-        // wm*64 + b*16 + lr (b = 0..3) and the 16 contiguous columns n0 .. n0+15; a 16-lane group covers 16 rows x
-        // 64 (bf16: 32) bytes per store instruction.  The output may alias the residual (x += ...), so the compiler
-        // would keep every row group's reads behind the previous group's stores: reads are issued by hand, two
-        // groups ahead.
+        // wm*RB*16 + b*16 + lr (b = 0..RB-1) and four 4-column runs (ntf_run_off); the four lanes of a row cover a contiguous
+        // 64-byte segment per store instruction.  The output may alias the residual (x += ...), so the compiler would keep
+        // every row group's reads behind the previous group's stores: reads are issued by hand, two groups ahead.
         const int cm_blk = m_blk;
-        const int n0 = n_blk + wn * 64 + lg * 16;
-        const bool col_ok = n0 < N;   // N % 16 == 0 on this path: a lane's 16 columns are all in or all out
-        const int n0c = col_ok ? n0 : 0;
-        int drow[4], arow[4];
+        int roff[4];      // column of run a (clamped to 0 when the run lies past N: reads stay in bounds, stores are skipped)
+        bool rok[4];      // N % 16 == 0 on this path: a run (and a 16-byte pair of bf16 runs) is all in or all out
 #pragma unroll
-        for (int b = 0; b < 4; ++b) {
-            const int m = cm_blk + wm * 64 + b * 16 + lr;
+        for (int a = 0; a < 4; ++a) {
+            const int col = n_blk + wn * 64 + ntf_run_off<CG>(lg, a);
+            rok[a] = col < N;
+            roff[a] = rok[a] ? col : 0;
+        }
+        int drow[RB], arow[RB];
+#pragma unroll
+        for (int b = 0; b < RB; ++b) {
+            const int m = cm_blk + wm * (RB * 16) + b * 16 + lr;
             drow[b] = -1;
             arow[b] = -1;
             if (m < M) {
@@ -389,18 +424,60 @@ __global__ __launch_bounds__(GT) __attribute__((amdgpu_waves_per_eu(3))) void ge
                 arow[b] = (by_arow && g.a_rows) ? g.a_rows[m] : drow[b];
             }
         }
-        uint4 pf[2][4];   // raw residual rows (4 x 16 B of float32), or -- without a residual -- aux rows (2 x 16 B of bf16)
+        uint4 pf[2][4];   // raw residual rows (4 runs x 16 B of float32), or -- without a residual -- aux rows (bf16: 16 B per run pair / 8 B per run)
         auto prefetch = [&](int b, uint4 (&dst)[4]) {   // unconditional: rows that will not be stored read a clamped address
             if (has_res) {
                 const long long rb = max(by_arow ? arow[b] : drow[b], 0);
-                const uint4* src = reinterpret_cast<const uint4*>(g.res + (size_t)(g.res_mod > 0 ? rb % g.res_mod : rb) * N + n0c);
+                const float* src = g.res + (size_t)(g.res_mod > 0 ? rb % g.res_mod : rb) * N;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) dst[i] = src[i];
+                for (int a = 0; a < 4; ++a) dst[a] = *reinterpret_cast<const uint4*>(src + roff[a]);
             } else if (use_aux) {
-                const int m = min(cm_blk + wm * 64 + b * 16 + lr, M - 1);
-                const uint4* src = reinterpret_cast<const uint4*>(aux + (size_t)m * N + n0c);
-                dst[0] = src[0];
-                dst[1] = src[1];
+                const int m = min(cm_blk + wm * (RB * 16) + b * 16 + lr, M - 1);
+                const bf16_t* src = aux + (size_t)m * N;
+                if constexpr (CG == 8) {
+                    dst[0] = *reinterpret_cast<const uint4*>(src + roff[0]);
+                    dst[1] = *reinterpret_cast<const uint4*>(src + roff[2]);
+                } else {
+#pragma unroll
+                    for (int a = 0; a < 4; ++a) {
+                        const uint2 t = *reinterpret_cast<const uint2*>(src + roff[a]);
+                        dst[a] = make_uint4(t.x, t.y, 0u, 0u);
+                    }
+                }
+            }
+        };
+        // 16 values of a lane <-> its four runs
+        auto ld_runs = [&](const float* row, float (&v)[16]) {
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                const float4 t = *reinterpret_cast<const float4*>(row + roff[a]);
+                v[4 * a] = t.x; v[4 * a + 1] = t.y; v[4 * a + 2] = t.z; v[4 * a + 3] = t.w;
+            }
+        };
+        auto ld_runs_lp = [&](const bf16_t* row, float (&v)[16]) {
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                const uint2 t = *reinterpret_cast<const uint2*>(row + roff[a]);
+                v[4 * a] = __uint_as_float(t.x << 16); v[4 * a + 1] = __uint_as_float(t.x & 0xffff0000u);
+                v[4 * a + 2] = __uint_as_float(t.y << 16); v[4 * a + 3] = __uint_as_float(t.y & 0xffff0000u);
+            }
+        };
+        auto st_runs = [&](float* row, const float (&v)[16]) {
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+                if (rok[a]) *reinterpret_cast<float4*>(row + roff[a]) = make_float4(v[4 * a], v[4 * a + 1], v[4 * a + 2], v[4 * a + 3]);
+        };
+        auto st_runs_lp = [&](bf16_t* row, const float (&v)[16]) {
+            if constexpr (CG == 8) {
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+                    if (rok[2 * h])
+                        *reinterpret_cast<uint4*>(row + roff[2 * h]) = make_uint4(pack_bf16(v[8 * h], v[8 * h + 1]), pack_bf16(v[8 * h + 2], v[8 * h + 3]),
+                                                                                  pack_bf16(v[8 * h + 4], v[8 * h + 5]), pack_bf16(v[8 * h + 6], v[8 * h + 7]));
+            } else {
+#pragma unroll
+                for (int a = 0; a < 4; ++a)
+                    if (rok[a]) *reinterpret_cast<uint2*>(row + roff[a]) = make_uint2(pack_bf16(v[4 * a], v[4 * a + 1]), pack_bf16(v[4 * a + 2], v[4 * a + 3]));
             }
         };
         if (has_res || use_aux) {
@@ -408,33 +485,41 @@ __global__ __launch_bounds__(GT) __attribute__((amdgpu_waves_per_eu(3))) void ge
             prefetch(1, pf[1]);
         }
 
-        f32x4_t acc[4][4];
+        f32x4_t acc[4][RB];
 #pragma unroll
         for (int a = 0; a < 4; ++a)
 #pragma unroll
-            for (int b = 0; b < 4; ++b) acc[a][b] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+            for (int b = 0; b < RB; ++b) acc[a][b] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
         for (int kt = 0; kt < nk; ++kt) {
             // stages allowed to stay in flight behind stage kt; a later tile's first step also retires the previous
             // epilogue's stores and this tile's prefetches, whose number is not known: plain vmcnt(0)
             const int rem = (kt == 0 && !first) ? 0 : min(nk - 1 - kt, PF - 1);
-            if (rem >= 3) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-            else if (rem == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-            else if (rem == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if constexpr (NDMA == 4) {
+                if (rem >= 3) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+                else if (rem == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                else if (rem == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            } else {
+                static_assert(NDMA == 3, "vmcnt table covers 3 or 4 LDS-DMA pieces per wave and stage");
+                if (rem >= 3) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+                else if (rem == 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+                else if (rem == 1) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
             if (kt + PF < nk) issue(kt + PF);
             const unsigned char* st = smem + (kt % NST) * STAGE;
-            short8_t w8[4], x8[4];
+            short8_t w8[4], x8[RB];
 #pragma unroll
             for (int a = 0; a < 4; ++a) w8[a] = *reinterpret_cast<const short8_t*>(st + fw[a]);
 #pragma unroll
-            for (int b = 0; b < 4; ++b) x8[b] = *reinterpret_cast<const short8_t*>(st + fx[b]);
+            for (int b = 0; b < RB; ++b) x8[b] = *reinterpret_cast<const short8_t*>(st + fx[b]);
 #pragma unroll
             for (int a = 0; a < 4; ++a)
 #pragma unroll
-                for (int b = 0; b < 4; ++b)
+                for (int b = 0; b < RB; ++b)
                     acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, w8[a]), __builtin_bit_cast(bf16x8_t, x8[b]),
                                                                         acc[a][b], 0, 0, 0);
         }
@@ -453,21 +538,21 @@ __global__ __launch_bounds__(GT) __attribute__((amdgpu_waves_per_eu(3))) void ge
         }
 
         // ---- epilogue straight from the accumulators (its stores drain under the next tile's main loop)
-        if (col_ok) {
+        {
         float bias16[16];
 #pragma unroll
         for (int e = 0; e < 16; ++e) bias16[e] = 0.f;
-        if (has_bias) ld16(g.bias + n0, bias16);
+        if (has_bias) ld_runs(g.bias, bias16);
         // arithmetic and stores, in place in the accumulator registers
 #pragma unroll
-        for (int bb = 0; bb < 4; ++bb)
+        for (int bb = 0; bb < RB; ++bb)
 #pragma unroll
             for (int a = 0; a < 4; ++a)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) acc[a][bb][j] += bias16[a * 4 + j];
 #pragma unroll
-        for (int b = 0; b < 4; ++b) {
-            const int m = cm_blk + wm * 64 + b * 16 + lr;
+        for (int b = 0; b < RB; ++b) {
+            const int m = cm_blk + wm * (RB * 16) + b * 16 + lr;
             const long long d = drow[b];
             float cur[16];
             if (has_res) {
@@ -476,7 +561,7 @@ __global__ __launch_bounds__(GT) __attribute__((amdgpu_waves_per_eu(3))) void ge
                     cur[4 * i] = __uint_as_float(pf[b & 1][i].x); cur[4 * i + 1] = __uint_as_float(pf[b & 1][i].y);
                     cur[4 * i + 2] = __uint_as_float(pf[b & 1][i].z); cur[4 * i + 3] = __uint_as_float(pf[b & 1][i].w);
                 }
-            } else {
+            } else if constexpr (CG == 8) {
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
                     const unsigned w[4] = {pf[b & 1][i].x, pf[b & 1][i].y, pf[b & 1][i].z, pf[b & 1][i].w};
@@ -486,28 +571,34 @@ __global__ __launch_bounds__(GT) __attribute__((amdgpu_waves_per_eu(3))) void ge
                         cur[8 * i + 2 * k + 1] = __uint_as_float(w[k] & 0xffff0000u);
                     }
                 }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    cur[4 * i] = __uint_as_float(pf[b & 1][i].x << 16); cur[4 * i + 1] = __uint_as_float(pf[b & 1][i].x & 0xffff0000u);
+                    cur[4 * i + 2] = __uint_as_float(pf[b & 1][i].y << 16); cur[4 * i + 3] = __uint_as_float(pf[b & 1][i].y & 0xffff0000u);
+                }
             }
-            if (b + 2 < 4 && (has_res || use_aux)) prefetch(b + 2, pf[b & 1]);
+            if (b + 2 < RB && (has_res || use_aux)) prefetch(b + 2, pf[b & 1]);
             if (d < 0) continue;
             float v[16];
             if (by_arow && arow[b] < 0) {
 #pragma unroll
                 for (int e = 0; e < 16; ++e) v[e] = 0.f;
-                if (out_lp) st16(out_lp + (size_t)d * N + n0, v);
-                if (g.out_f32) st16(g.out_f32 + (size_t)d * N + n0, v);
+                if (out_lp) st_runs_lp(out_lp + (size_t)d * N, v);
+                if (g.out_f32) st_runs(g.out_f32 + (size_t)d * N, v);
                 continue;
             }
 #pragma unroll
             for (int a = 0; a < 4; ++a)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) v[a * 4 + j] = acc[a][b][j];
-            if (has_pre && !pre_grad) st16(pre + (size_t)d * N + n0, v);
+            if (has_pre && !pre_grad) st_runs_lp(pre + (size_t)d * N, v);
             if (act == STAR_ACT_GELU) {
                 if (has_pre && pre_grad) {
                     float dv[16];
 #pragma unroll
                     for (int e = 0; e < 16; ++e) gelu_both(v[e], v[e], dv[e]);
-                    st16(pre + (size_t)d * N + n0, dv);
+                    st_runs_lp(pre + (size_t)d * N, dv);
                 } else {
 #pragma unroll
                     for (int e = 0; e < 16; ++e) v[e] = gelu_f(v[e]);
@@ -517,14 +608,14 @@ __global__ __launch_bounds__(GT) __attribute__((amdgpu_waves_per_eu(3))) void ge
                     float dv[16];
 #pragma unroll
                     for (int e = 0; e < 16; ++e) dv[e] = v[e] > 0.f ? 1.f : 0.f;
-                    st16(pre + (size_t)d * N + n0, dv);
+                    st_runs_lp(pre + (size_t)d * N, dv);
                 }
 #pragma unroll
                 for (int e = 0; e < 16; ++e) v[e] = fmaxf(v[e], 0.f);
             } else if (use_aux) {
                 if (has_res) {   // both a residual and an activation gradient: the aux row was not prefetched
                     float t[16];
-                    ld16(aux + (size_t)m * N + n0, t);
+                    ld_runs_lp(aux + (size_t)m * N, t);
 #pragma unroll
                     for (int e = 0; e < 16; ++e)
                         v[e] = act == STAR_ACT_DGELU ? v[e] * dgelu_f(t[e]) : (act == STAR_ACT_MULAUX ? v[e] * t[e] : (t[e] > 0.f ? v[e] : 0.f));
@@ -546,12 +637,12 @@ __global__ __launch_bounds__(GT) __attribute__((amdgpu_waves_per_eu(3))) void ge
             if (has_res2) {
                 const int rr = (m / g.res2_div) % g.res2_mod;
                 float t2[16];
-                ld16(g.res2 + (size_t)rr * N + n0, t2);
+                ld_runs(g.res2 + (size_t)rr * N, t2);
 #pragma unroll
                 for (int e = 0; e < 16; ++e) v[e] += t2[e];
             }
-            if (out_lp) st16(out_lp + (size_t)d * N + n0, v);
-            if (g.out_f32) st16(g.out_f32 + (size_t)d * N + n0, v);
+            if (out_lp) st_runs_lp(out_lp + (size_t)d * N, v);
+            if (g.out_f32) st_runs(g.out_f32 + (size_t)d * N, v);
         }
         }
         if (!more) break;
@@ -560,19 +651,50 @@ __global__ __launch_bounds__(GT) __attribute__((amdgpu_waves_per_eu(3))) void ge
     }
 }
 
-template <int NST, int EPI>
-static void launch_nt_fast_epi(const StarGemm* g, hipStream_t s) {
-    const int tiles = cdiv(g->M, 128) * cdiv(g->N, 128);
-    const size_t lds = (size_t)NST * 256 * 64;   // the ring only: the epilogue does not stage through LDS
+template <int NST, int EPI, int WM, int WN, int RB, int CG>
+static void launch_nt_fast_cg(const StarGemm* g, hipStream_t s) {
+    constexpr int BM = WM * RB * 16, BN = WN * 64;
+    const int tiles = cdiv(g->M, BM) * cdiv(g->N, BN);
+    const size_t lds = (size_t)NST * (BM + BN) * 64;   // the ring only: the epilogue does not stage through LDS
     static bool attr_done = false;
     if (!attr_done && lds > 48 * 1024) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_fast_kernel<NST, EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_fast_kernel<NST, EPI, WM, WN, RB, CG>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)lds);
         attr_done = true;
     }
     // The kernel can walk several tiles per block (grid < tiles), prefilling the next tile's ring under the epilogue.
-    // Measured on MI355X this is no faster than one tile per block (time = main loops + epilogue bytes / ~5.5 TB/s
-    // either way), so every tile gets its own block and the hardware dispatcher balances the tail.
-    hipLaunchKernelGGL((gemm_nt_fast_kernel<NST, EPI>), dim3(tiles), dim3(GT), lds, s, *g);
+    // Measured on MI355X this is no faster than one tile per block, so every tile gets its own block and the hardware
+    // dispatcher balances the tail.
+    hipLaunchKernelGGL((gemm_nt_fast_kernel<NST, EPI, WM, WN, RB, CG>), dim3(tiles), dim3(WM * WN * 64), lds, s, *g);
+}
+
+template <int NST, int EPI, int WM, int WN, int RB>
+static void launch_nt_fast_geo(const StarGemm* g, hipStream_t s) {
+    // column groups by output type: any bf16 output -> 8 columns per 16-byte store, float32 only -> 4
+    if (g->out_lp || g->pre) launch_nt_fast_cg<NST, EPI, WM, WN, RB, 8>(g, s);
+    else launch_nt_fast_cg<NST, EPI, WM, WN, RB, 4>(g, s);
+}
+
+// Geometry by epilogue and shape, from measurements at M = 40 960 on MI355X (profiles/r01_d_gemm_geometry.log):
+//   plain Linear (bias only, bf16 or f32 out): the 256 x 128 tile wins by 10-20 % (no spills at 128 registers, 16 waves per CU);
+//   fc1 + GELU at N >= 1536: the 256 x 256 tile wins by 12 %;  residual / aux epilogues: the 128 x 128 tile (the larger tiles
+//   spill or halve the occupancy).  STAR_AMD_GEMM_GEO=0/1/2 forces one geometry (A/B measurements, tests of every variant).
+template <int EPI>
+static int nt_geometry(const StarGemm* g) {
+    static const char* env = getenv("STAR_AMD_GEMM_GEO");
+    if (env && env[0] >= '0' && env[0] <= '2') return env[0] - '0';
+    if (EPI == EPI_LINEAR && (long long)cdiv(g->M, 256) * cdiv(g->N, 128) >= star_num_cus()) return 1;
+    if (EPI == EPI_GELU_GRAD && g->N >= 1536 && (long long)cdiv(g->M, 256) * cdiv(g->N, 256) >= 2 * star_num_cus()) return 2;
+    return 0;
+}
+
+template <int NST, int EPI>
+static void launch_nt_fast_epi(const StarGemm* g, hipStream_t s) {
+    switch (EPI == EPI_GENERIC ? 0 : nt_geometry<EPI>(g)) {   // the run-time epilogue needs too many registers for the larger tiles
+        case 2: launch_nt_fast_geo<NST, EPI, 2, 4, 8>(g, s); break;
+        case 1: launch_nt_fast_geo<NST, EPI, 4, 2, 4>(g, s); break;
+        default: launch_nt_fast_geo<NST, EPI, 2, 2, 4>(g, s); break;
+    }
 }
 template <int NST>
 static int launch_nt_fast(const StarGemm* g, hipStream_t s) {
