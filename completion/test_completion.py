@@ -27,7 +27,7 @@ def main(args):
     else:
         model = multiagent_mae.__dict__[args.mae_model](norm_pix_loss=args.norm_pix_loss, time_stamp=args.time_stamp, mask_method=args.mask)
     if args.resume:
-        checkpoint = torch.load(args.resume, map_location="cpu", weights_only=False)
+        checkpoint = torch.load(args.resume, map_location="cpu", weights_only=True)
         model.load_state_dict(checkpoint["model_state_dict"])
         print("Load model from {}, at epoch {}".format(args.resume, checkpoint["epoch"]))
     model = model.to(device).set_compute_dtype(args.dtype)

@@ -87,7 +87,7 @@ def main(args):
         files = glob.glob(os.path.join(args.auto_resume_path, args.com, cross, "completion_epoch_*.pth"))
         resume = max(files, key=os.path.getctime) if files else ""
     if resume:
-        checkpoint = torch.load(resume, map_location="cpu", weights_only=False)
+        checkpoint = torch.load(resume, map_location="cpu", weights_only=True)
         start_epoch = checkpoint["epoch"] + 1
         if args.fused_optimizer:
             model.load_state_dict(checkpoint["model_state_dict"])   # parameters are views of the flat buffer: copied in place
