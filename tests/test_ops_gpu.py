@@ -433,3 +433,47 @@ def test_warp_fuse_full_size_vs_c_oracle():
     out = ops.warp_fuse(torch.from_numpy(ind).to(DEV), ops.warp_thetas(torch.from_numpy(trans)).to(DEV), torch.from_numpy(na).to(DEV), B,
                         ego=torch.from_numpy(ego).to(DEV), binary=True)
     assert np.array_equal(out.cpu().numpy(), want)
+
+
+def test_warp_fuse_edge_cases_vs_oracle():
+    """num_agent 0 (nothing fused), 1 (only the ego), a count larger than A (clamped as range() over a too-short list would
+    not be: the oracle is given A); identity poses (every neighbour lands on itself); translations far outside the map
+    (every sample padded with zeros); non-finite pose entries (comparisons fail -> zero padding, like grid_sample)."""
+    from oracle import c_oracle as OC
+    rng = np.random.RandomState(17)
+    B, A, C, S = 4, 3, 13, 32
+    ind = (rng.rand(A * B, C, S, S) < 0.2).astype(np.uint8)
+    trans = np.zeros((B, A, A, 4, 4))
+    for b in range(B):
+        for i in range(A):
+            for j in range(A):
+                trans[b, i, j] = np.eye(4)
+    trans[1, :, :, 0, 3] = 1.0e4        # scene 1: far outside
+    trans[1, :, :, 1, 3] = -3.0e3
+    for i in range(A):                 # scene 3: generic poses
+        for j in range(A):
+            yaw = rng.uniform(-math.pi, math.pi)
+            trans[3, i, j] = [[math.cos(yaw), -math.sin(yaw), 0, rng.uniform(-30, 30)], [math.sin(yaw), math.cos(yaw), 0, rng.uniform(-30, 30)],
+                              [0, 0, 1, 0], [0, 0, 0, 1]]
+    for counts in ([0, 1, 3, 3], [3, 3, 1, 0], [1, 0, 0, 2]):
+        na = np.repeat(np.array(counts)[:, None], A, axis=1)
+        want = OC.late_fusion(ind.astype(np.float32), trans, na, B)
+        assert np.array_equal(want, O.late_fusion(ind.astype(np.float32), trans, na, B))
+        for binary in (False, True):
+            out = ops.warp_fuse(torch.from_numpy(ind).to(DEV), ops.warp_thetas(torch.from_numpy(trans)).to(DEV), torch.from_numpy(na).to(DEV), B,
+                                binary=binary)
+            assert np.array_equal(out.cpu().numpy(), want), (counts, binary)
+    # identity poses with all agents: every ego map is the union of the scene's maps
+    na = np.full((B, A), A)
+    out = ops.warp_fuse(torch.from_numpy(ind).to(DEV), ops.warp_thetas(torch.from_numpy(trans)).to(DEV), torch.from_numpy(na).to(DEV), B, binary=True)
+    x = ind.reshape(A, B, C, S, S)
+    assert np.array_equal(out.cpu().numpy().reshape(A, B, C, S, S)[:, 0], np.broadcast_to(x[:, 0].max(0), (A, C, S, S)).astype(np.float32))
+    assert np.array_equal(out.cpu().numpy().reshape(A, B, C, S, S)[:, 1], x[:, 1].astype(np.float32))      # far outside: only the ego survives
+    # non-finite poses: the kernel must neither fault nor invent occupancy
+    bad = trans.copy()
+    bad[0, 0, 1, 0, 3] = np.nan
+    bad[0, 1, 0, 0, 0] = np.inf
+    out = ops.warp_fuse(torch.from_numpy(ind).to(DEV), ops.warp_thetas(torch.from_numpy(bad)).to(DEV), torch.from_numpy(na).to(DEV), B, binary=True)
+    got = out.cpu().numpy().reshape(A, B, C, S, S)
+    assert set(np.unique(got)) <= {0.0, 1.0}
+    assert (got[0, 0] >= x[0, 0]).all() and (got[0, 0] <= np.maximum(x[0, 0], x[2, 0])).all()   # agent 1's NaN pose contributes nothing to ego 0
