@@ -30,4 +30,10 @@ elif what == "wgrad":
     x = torch.randn(M, K, generator=g).to(dev).bfloat16()
     for _ in range(3):
         ops.gemm_wgrad(dy, x)
+elif what == "vq":
+    K, E = int(sys.argv[2]), int(sys.argv[3])
+    x = torch.relu(torch.randn(40960, E, generator=g)).to(dev)
+    cb = (torch.randn(K, E, generator=g) * 0.5).abs().to(dev)
+    for _ in range(3):
+        ops.vq_assign(x, cb, 0)
 torch.cuda.synchronize()
