@@ -19,6 +19,8 @@ class CoModule(object):
         self.optimizer = optimizer
         self.parallel = parallel
         self.scheduler = None            # only the 'late' / 'vqvae' baselines of the reference use one
+        self._loss_host = None           # pinned scalar + event for the early loss read-back of the fused step
+        self._loss_event = None
         if com not in ("ind_mae", "joint_mae", "vqstar"):
             raise NotImplementedError("star_amd accelerates the 'ind_mae' and 'vqstar' completion paths; com=%r is out of scope" % (com,))
 
@@ -47,10 +49,19 @@ class CoModule(object):
         """Loss readback, finite check and parameter update shared by the mae and vqstar steps."""
         fused = trainable and getattr(self.optimizer, "is_star_flat", False)
         if fused:
-            # enqueue the whole backward (and the bucketed gradient all-reduce) BEFORE the host reads the loss,
-            # so the GPU never idles on the .item() round trip; the finite check still precedes the update
+            # The loss is copied to pinned host memory right behind the forward kernels, THEN the whole backward (and the
+            # bucketed gradient all-reduce) is enqueued; the host waits for the copy only, so the finite check still precedes
+            # the update while the GPU never idles on a round trip -- the optimizer launch is queued behind the backward.
+            if self._loss_host is None:
+                self._loss_host = torch.empty((), dtype=torch.float32).pin_memory()
+                self._loss_event = torch.cuda.Event()
+            self._loss_host.copy_(loss.detach(), non_blocking=True)
+            self._loss_event.record()
             loss.backward()
-        loss_value = loss.item()
+            self._loss_event.synchronize()
+            loss_value = float(self._loss_host)
+        else:
+            loss_value = loss.item()
         if not math.isfinite(loss_value):
             print("Loss is {}, stopping training".format(loss_value))
             sys.exit(1)
