@@ -436,6 +436,32 @@ def vector_quantize(x, codebook, commitment):
     return loss, quantized, perplexity, indices
 
 
+def vector_quantize_ema(x, codebook, ema_w, ema_cluster_size, commitment, decay, training, epsilon=1e-5):
+    """STARVectorQuantizerEMA.forward (star/models/mae_base.py:197-253) after its one-off k-means initialisation.
+    -> (loss, quantized (straight-through), perplexity, indices, new_codebook, new_ema_w, new_cluster_size); the three
+    state tensors are returned unchanged when not training."""
+    flat = x.reshape(-1, codebook.shape[1])
+    distances = (torch.sum(flat ** 2, dim=1, keepdim=True) + torch.sum(codebook ** 2, dim=1) - 2 * torch.matmul(flat, codebook.t()))
+    indices = torch.argmin(distances, dim=1)
+    encodings = torch.zeros(indices.shape[0], codebook.shape[0])
+    encodings.scatter_(1, indices.unsqueeze(1), 1)
+    quantized = torch.matmul(encodings, codebook).view(x.shape)
+    new_cb, new_w, new_cs = codebook, ema_w, ema_cluster_size
+    if training:
+        new_cs = ema_cluster_size * decay + (1 - decay) * torch.sum(encodings, 0)
+        n = torch.sum(new_cs)
+        new_cs = (new_cs + epsilon) / (n + codebook.shape[0] * epsilon) * n
+        dw = torch.matmul(encodings.t(), flat.detach())
+        new_w = ema_w * decay + (1 - decay) * dw
+        new_cb = new_w / new_cs.unsqueeze(1)
+    e_latent_loss = F.mse_loss(quantized.detach(), x)
+    loss = commitment * e_latent_loss
+    quantized = x + (quantized - x).detach()
+    avg_probs = torch.mean(encodings, dim=0)
+    perplexity = torch.exp(-torch.sum(avg_probs * torch.log(avg_probs + 1e-10)))
+    return loss, quantized, perplexity, indices, new_cb, new_w, new_cs
+
+
 def run(sd, cfg, imgs1, imgs_next, trans, num_agent, batch, mask_ratio=0.75, infer=False, noise=None, taps=None):
     """forward (multiagent_mae.py:1084-1103) / inference (:1105-1125).
     Returns (loss, result, latent, ind_result, pred).  With cfg["vq"] (VQ-STAR, star/models/VQSTAR.py:421-470) the
@@ -443,7 +469,14 @@ def run(sd, cfg, imgs1, imgs_next, trans, num_agent, batch, mask_ratio=0.75, inf
     perplexity, vq_indices."""
     latent, mask, ids_restore = encode(sd, cfg, imgs1, imgs_next, mask_ratio, noise, taps)
     if cfg.get("vq"):
-        vq_loss, quantized, perplexity, vq_idx = vector_quantize(latent, sd["_vq_star._embedding.weight"], cfg["commitment"])
+        if cfg.get("vq_decay", 0.0) > 0.0:     # EMA codebook: the updated state goes to taps["vq_state"]
+            vq_loss, quantized, perplexity, vq_idx, ncb, nw, ncs = vector_quantize_ema(
+                latent, sd["_vq_star._embedding.weight"].detach(), sd["_vq_star._ema_w"].detach(), sd["_vq_star._ema_cluster_size"],
+                cfg["commitment"], cfg["vq_decay"], training=cfg.get("vq_training", not infer))
+            if taps is not None:
+                taps["vq_state"] = (ncb, nw, ncs)
+        else:
+            vq_loss, quantized, perplexity, vq_idx = vector_quantize(latent, sd["_vq_star._embedding.weight"], cfg["commitment"])
         pred = decode(sd, cfg, quantized, mask, ids_restore, taps)
         if taps is not None:
             taps["mask"], taps["ids_restore"], taps["pred"] = mask, ids_restore, pred

@@ -45,11 +45,11 @@ def gen_quantizer(mb):
     print("wrote vq_quantizer")
 
 
-def gen_model_case(VQ, name, T, mask, B, A, num_agent, S, mode, seed, K, E, cc, mask_ratio=0.75):
+def gen_model_case(VQ, name, T, mask, B, A, num_agent, S, mode, seed, K, E, cc, mask_ratio=0.75, decay=0.):
     torch.manual_seed(0)
     model = VQ.VQSTARViT(img_size=S, patch_size=8, in_chans=13, embed_dim=32, depth=2, num_heads=2, decoder_embed_dim=32, decoder_depth=2,
                          decoder_num_heads=2, mlp_ratio=4, norm_layer=partial(nn.LayerNorm, eps=1e-6), decoder_head="mlp", time_stamp=T,
-                         mask_method=mask, decay=0., commitment_cost=cc, num_vq_embeddings=K, vq_embedding_dim=E)
+                         mask_method=mask, decay=decay, commitment_cost=cc, num_vq_embeddings=K, vq_embedding_dim=E)
     torch.manual_seed(7)
     with torch.no_grad():
         model.decoder_temp_embed.normal_(std=0.02)
@@ -57,7 +57,12 @@ def gen_model_case(VQ, name, T, mask, B, A, num_agent, S, mode, seed, K, E, cc, 
             if n_.endswith(".bias") or "norm" in n_:
                 p.add_(torch.randn_like(p) * 0.05)
         model._vq_star._embedding.weight.mul_(0.3).abs_()       # codes inside the ReLU latent's range: many codes in use
+        if decay > 0:      # EMA variant: skip the k-means re-initialisation (scipy RNG), start from a consistent state
+            model._vq_star.data_initialized = 1
+            model._vq_star._ema_cluster_size.fill_(1.5)
+            model._vq_star._ema_w.data.copy_(model._vq_star._embedding.weight * 1.5)
     model.train() if mode == "train" else model.eval()
+    sd_before = {k: v.detach().clone() for k, v in model.state_dict().items()}
     rng = np.random.RandomState(seed)
     bev, nxt, teacher = G.make_inputs(seed, B, A, T, S)
     trans = torch.from_numpy(G.make_trans(rng, B, A))
@@ -123,7 +128,12 @@ def gen_model_case(VQ, name, T, mask, B, A, num_agent, S, mode, seed, K, E, cc, 
     d = (lat ** 2).sum(1, keepdim=True) + (cb ** 2).sum(1, keepdim=True).t() - 2 * lat @ cb.t()
     top2 = torch.topk(d, 2, dim=1, largest=False).values
     out["vq_margin"] = (top2[:, 1] - top2[:, 0]).numpy()
-    np.savez_compressed(os.path.join(G.OUT, "sd_" + name + ".npz"), **{k: v.numpy() for k, v in model.state_dict().items()})
+    if decay > 0:      # state AFTER the step (mae_base.py:228-241 replaces the three tensors in training mode)
+        out["decay"] = np.array(decay)
+        out["post_embedding"] = model._vq_star._embedding.weight.detach().numpy()
+        out["post_ema_w"] = model._vq_star._ema_w.detach().numpy()
+        out["post_cluster_size"] = model._vq_star._ema_cluster_size.detach().numpy()
+    np.savez_compressed(os.path.join(G.OUT, "sd_" + name + ".npz"), **{k: v.numpy() for k, v in sd_before.items()})
     if mode == "train":
         for k, p in model.named_parameters():
             out["grad_" + k] = p.grad.numpy() if p.grad is not None else np.zeros((0,), np.float32)
@@ -139,6 +149,8 @@ def main():
     gen_model_case(VQ, "vq_T1_comp_train", 1, "complement", B=1, A=5, num_agent=[5], S=32, mode="train", seed=21, K=64, E=32, cc=0.25)
     gen_model_case(VQ, "vq_T3_comp_infer", 3, "complement", B=2, A=5, num_agent=[5, 3], S=32, mode="infer", seed=22, K=96, E=16, cc=0.25)
     gen_model_case(VQ, "vq_T2_rand_train", 2, "random", B=1, A=5, num_agent=[4], S=32, mode="train", seed=23, K=32, E=64, cc=0.5, mask_ratio=0.5)
+    gen_model_case(VQ, "vqema_T2_comp_train", 2, "complement", B=1, A=5, num_agent=[5], S=32, mode="train", seed=24, K=48, E=32, cc=0.25, decay=0.9)
+    gen_model_case(VQ, "vqema_T1_comp_infer", 1, "complement", B=1, A=5, num_agent=[3], S=32, mode="infer", seed=25, K=48, E=32, cc=0.25, decay=0.9)
 
 
 if __name__ == "__main__":

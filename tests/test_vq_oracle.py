@@ -6,7 +6,7 @@ import torch
 
 from golden_util import GOLD
 from oracle import star_oracle as O
-from vq_util import VQ_CASES, VQ_DIMS, VQCase
+from vq_util import VQ_CASES, VQ_DIMS, VQ_EMA_CASES, VQCase
 
 
 @pytest.mark.parametrize("tag", ["a", "b", "c"])
@@ -23,11 +23,11 @@ def test_quantizer_alone(tag):
     torch.testing.assert_close(cb.grad, torch.from_numpy(z[tag + "_dcodebook"]), rtol=1e-5, atol=1e-8)
 
 
-@pytest.mark.parametrize("name", VQ_CASES)
+@pytest.mark.parametrize("name", VQ_CASES + VQ_EMA_CASES)
 def test_vq_model_case(name):
     c = VQCase(name)
     cfg = O.make_cfg(img=c.S, T=c.T, mask=c.mask, inter=c.E, **VQ_DIMS)
-    cfg.update(vq=True, commitment=c.cc)
+    cfg.update(vq=True, commitment=c.cc, vq_decay=c.decay)
     sd = O.trainable(c.sd) if c.train else c.sd
     taps = {}
     with torch.set_grad_enabled(c.train):
@@ -52,3 +52,10 @@ def test_vq_model_case(name):
                     assert sd[k].grad is None, k
                 else:
                     torch.testing.assert_close(sd[k].grad, g, rtol=1e-4, atol=1e-6, msg=lambda m: k + ": " + m)
+        if c.decay > 0:     # EMA codebook: the state the reference holds after the step (unchanged in eval mode)
+            ncb, nw, ncs = taps["vq_state"]
+            torch.testing.assert_close(ncs, torch.from_numpy(c.z["post_cluster_size"]), rtol=1e-6, atol=1e-7)
+            torch.testing.assert_close(nw, torch.from_numpy(c.z["post_ema_w"]), rtol=1e-6, atol=1e-7)
+            torch.testing.assert_close(ncb, torch.from_numpy(c.z["post_embedding"]), rtol=1e-5, atol=1e-7)
+            if not c.train:
+                assert torch.equal(ncb, c.sd["_vq_star._embedding.weight"]) and torch.equal(ncs, c.sd["_vq_star._ema_cluster_size"])

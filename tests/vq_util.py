@@ -7,6 +7,7 @@ import torch
 from golden_util import GOLD, unpack
 
 VQ_CASES = ["vq_T1_comp_train", "vq_T3_comp_infer", "vq_T2_rand_train"]
+VQ_EMA_CASES = ["vqema_T2_comp_train", "vqema_T1_comp_infer"]
 VQ_DIMS = dict(patch=8, chans=13, dim=32, depth=2, heads=2, ddim=32, ddepth=2, dheads=2)
 
 
@@ -18,6 +19,7 @@ class VQCase:
         self.mask = "random" if rnd else "complement"
         self.train = bool(train)
         self.mask_ratio, self.cc = float(z["mask_ratio"]), float(z["cc"])
+        self.decay = float(z["decay"]) if "decay" in z.files else 0.0
         self.bev = torch.from_numpy(unpack(z["bev_bits"], z["bev_shape"]))
         self.next = torch.from_numpy(unpack(z["next_bits"], z["next_shape"])) if self.T > 1 else torch.zeros(self.A * self.B, 0)
         self.teacher = torch.from_numpy(unpack(z["teacher_bits"], z["teacher_shape"]))
