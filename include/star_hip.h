@@ -238,22 +238,31 @@ int star_voxel_scatter(const void* idx, int idx_is64, const int64_t* offsets, co
  *   q_f32 [M, E] / q_lp [M, E] in `dt` (each optional) = codebook[idx];
  *   part float32 [star_vq_nblocks(M)] per-workgroup sums of (q - x)^2 (optional);
  *   counts int32 [K] histogram of idx (optional; zeroed by the call).  E in {8,16,32,64,128}.
- * star_vq_finish: out3 = {loss = mse + commitment*mse, perplexity = exp(-sum p log(p+1e-10)), mse};
- *   loss_inout (optional) += loss, in stream order (the model's total loss, VQSTAR.py:443).
+ * star_vq_finish: out3 = {loss = mse + commitment*mse (ema != 0: commitment*mse alone, mae_base.py:244-245),
+ *   perplexity = exp(-sum p log(p+1e-10)), mse}; loss_inout (optional) += loss, in stream order (the model's total
+ *   loss, VQSTAR.py:443).
  * star_vq_bwd: dlat `dt` [M, E] = (dq + commitment * 2 (x - q)/(M E)) * [x > 0]  (straight-through estimator
  *   mae_base.py:166, then the compressor's ReLU); dcodebook float32 [K, E] = 2/(M E) * sum_{idx[m]=k} (q - x[m]),
  *   summed in a fixed order (deterministic), WRITTEN for every code; needs ws float32 [star_vq_bwd_ws(M,E,K)].
  *   Either output may be NULL.
+ * EMA codebook, STARVectorQuantizerEMA.forward in training mode (star/models/mae_base.py:228-241; `--decay` > 0):
+ *   star_vq_code_sums: dw float32 [K, E] = sum_{idx[m]=k} x[m, :] in a fixed order (encodings^T x); ws as star_vq_bwd;
+ *   star_vq_ema_update, in place: cluster_size [K] = cluster_size*decay + (1-decay)*counts, Laplace-smoothed with
+ *     epsilon; ema_w [K, E] = ema_w*decay + (1-decay)*dw; codebook = ema_w / cluster_size[:, None].  Between the two
+ *     calls a data-parallel job sums counts and dw over its ranks.
  * star_onehot_rows: the `encodings` matrix the reference returns from inference (mae_base.py:154-155),
  *   float32 [M, K], K % 4 == 0. */
 int star_vq_nblocks(int M);
 int star_vq_assign(const float* x, const float* codebook, int64_t* idx, float* q_f32, void* q_lp, float* part,
                    int32_t* counts, int M, int E, int K, int dt, void* stream);
 int star_vq_finish(const float* part, int nblocks, const int32_t* counts, int M, int E, int K, float commitment,
-                   float* out3, float* loss_inout, void* stream);
+                   int ema, float* out3, float* loss_inout, void* stream);
 int64_t star_vq_bwd_ws(int M, int E, int K);
 int star_vq_bwd(const void* dq, const float* x, const int64_t* idx, const float* codebook, void* dlat,
                 float* dcodebook, float* ws, int M, int E, int K, float commitment, int dt, void* stream);
+int star_vq_code_sums(const float* x, const int64_t* idx, float* dw, float* ws, int M, int E, int K, void* stream);
+int star_vq_ema_update(const int32_t* counts, const float* dw, float* codebook, float* ema_w, float* cluster_size,
+                       int E, int K, double decay, double epsilon, void* stream);
 int star_onehot_rows(const int64_t* idx, float* out, int M, int K, void* stream);
 
 #ifdef __cplusplus

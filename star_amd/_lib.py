@@ -66,7 +66,9 @@ _SIGS = {
     "star_iou_confusion": (C.c_int, [_P, _P, _P, _I, _I, _I, _I, _P]),
     "star_vq_nblocks": (C.c_int, [_I]),
     "star_vq_assign": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
-    "star_vq_finish": (C.c_int, [_P, _I, _P, _I, _I, _I, _F, _P, _P, _P]),
+    "star_vq_finish": (C.c_int, [_P, _I, _P, _I, _I, _I, _F, _I, _P, _P, _P]),
+    "star_vq_code_sums": (C.c_int, [_P, _P, _P, _P, _I, _I, _I, _P]),
+    "star_vq_ema_update": (C.c_int, [_P, _P, _P, _P, _P, _I, _I, C.c_double, C.c_double, _P]),
     "star_vq_bwd_ws": (C.c_int64, [_I, _I, _I]),
     "star_vq_bwd": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _I, _P]),
     "star_onehot_rows": (C.c_int, [_P, _P, _I, _I, _P]),

@@ -185,9 +185,10 @@ __global__ __launch_bounds__(VQ_THREADS) void vq_assign_kernel(const float* __re
     }
 }
 
-// out3[0] = vq loss, out3[1] = perplexity, out3[2] = mse; *loss_inout += vq loss (the model's total loss)
+// out3[0] = vq loss, out3[1] = perplexity, out3[2] = mse; *loss_inout += vq loss (the model's total loss).
+// ema: the EMA quantiser has no codebook term in its loss (mae_base.py:244-245): loss = cc * mse.
 __global__ __launch_bounds__(256) void vq_finish_kernel(const float* __restrict__ part, int nblk, const int* __restrict__ counts, int M, int E, int K,
-                                                        float cc, float* __restrict__ out3, float* __restrict__ loss_inout) {
+                                                        float cc, int ema, float* __restrict__ out3, float* __restrict__ loss_inout) {
     __shared__ float s_a[256], s_b[256];
     float a = 0.f, b = 0.f;
     for (int i = threadIdx.x; i < nblk; i += 256) a += part[i];
@@ -207,7 +208,7 @@ __global__ __launch_bounds__(256) void vq_finish_kernel(const float* __restrict_
     }
     if (threadIdx.x == 0) {
         const float mse = s_a[0] / ((float)M * (float)E);
-        const float loss = mse + cc * mse;
+        const float loss = ema ? cc * mse : mse + cc * mse;
         out3[0] = loss;
         out3[1] = expf(-s_b[0]);
         out3[2] = mse;
@@ -234,7 +235,9 @@ __global__ __launch_bounds__(256) void vq_bwd_rows_kernel(const T* __restrict__ 
 // A wave owns G codes x one chunk of rows and scans the chunk's indices (L2-resident); matches are taken in row order
 // from the ballot, four at a time so that four x-row loads are in flight (a collapsed codebook sends every row of the
 // chunk to ONE wave: the chunking bounds that chain to `rows_per` rows, the prefetch hides its load latency).
+// SUMX: accumulate x[m, :] alone -- the per-code row sums of the EMA codebook update (encodings^T x, mae_base.py:236).
 #define VQB_PF 4
+template <bool SUMX>
 __global__ __launch_bounds__(256) void vq_bwd_codes_kernel(const float* __restrict__ x, const int64_t* __restrict__ idx, const float* __restrict__ cb,
                                                            float* __restrict__ part, int M, int E, int K, int G, int rows_per) {
     extern __shared__ float vq_acc[];            // [4 waves][G][E]
@@ -264,7 +267,7 @@ __global__ __launch_bounds__(256) void vq_bwd_codes_kernel(const float* __restri
                 for (int u = 0; u < VQB_PF; ++u) xv[u] = tt[u] >= 0 ? x[(size_t)(m0 + tt[u]) * E + e] : 0.f;
 #pragma unroll
                 for (int u = 0; u < VQB_PF; ++u)
-                    if (tt[u] >= 0) acc[gg[u] * E + e] += cb[(size_t)(c0 + gg[u]) * E + e] - xv[u];
+                    if (tt[u] >= 0) acc[gg[u] * E + e] += SUMX ? xv[u] : cb[(size_t)(c0 + gg[u]) * E + e] - xv[u];
             }
         }
     }
@@ -329,11 +332,11 @@ extern "C" int star_vq_assign(const float* x, const float* codebook, int64_t* id
     return 0;
 }
 
-extern "C" int star_vq_finish(const float* part, int nblocks, const int32_t* counts, int M, int E, int K, float commitment, float* out3,
+extern "C" int star_vq_finish(const float* part, int nblocks, const int32_t* counts, int M, int E, int K, float commitment, int ema, float* out3,
                               float* loss_inout, void* stream) {
     STAR_CHECK(part && counts && out3, "star_vq_finish: null pointer");
     STAR_CHECK(nblocks > 0 && M > 0 && E > 0 && K > 0, "star_vq_finish: bad shape");
-    hipLaunchKernelGGL(vq_finish_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, part, nblocks, counts, M, E, K, commitment, out3, loss_inout);
+    hipLaunchKernelGGL(vq_finish_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, part, nblocks, counts, M, E, K, commitment, ema, out3, loss_inout);
     STAR_LAUNCH_CHECK("star_vq_finish");
     return 0;
 }
@@ -374,11 +377,67 @@ extern "C" int star_vq_bwd(const void* dq, const float* x, const int64_t* idx, c
         vq_bwd_plan(M, &C, &rp);
         const int G = K >= 1024 ? 8 : 2;
         const size_t lds = (size_t)4 * G * E * sizeof(float);
-        hipLaunchKernelGGL(vq_bwd_codes_kernel, dim3(cdiv(K, 4 * G), C), dim3(256), lds, s, x, idx, codebook, ws, M, E, K, G, rp);
+        hipLaunchKernelGGL(vq_bwd_codes_kernel<false>, dim3(cdiv(K, 4 * G), C), dim3(256), lds, s, x, idx, codebook, ws, M, E, K, G, rp);
         const int64_t n = (int64_t)K * E;
         hipLaunchKernelGGL(vq_bwd_codes_reduce_kernel, dim3(cdiv(n, 256)), dim3(256), 0, s, ws, dcodebook, n, C, inv);
     }
     STAR_LAUNCH_CHECK("star_vq_bwd");
+    return 0;
+}
+
+// EMA codebook update in place (star/models/mae_base.py:228-241), one block (K E is a few 100k elements):
+//   cs = cs * decay + (1 - decay) * counts;  n = sum(cs);  cs = (cs + eps) / (n + K eps) * n
+//   ema_w = ema_w * decay + (1 - decay) * dw;  codebook = ema_w / cs[:, None]
+__global__ __launch_bounds__(1024) void vq_ema_update_kernel(const int* __restrict__ counts, const float* __restrict__ dw, float* __restrict__ cb,
+                                                             float* __restrict__ ema_w, float* __restrict__ cs, int E, int K, float decay,
+                                                             float one_minus, float eps, float keps) {
+    __shared__ float red[1024];
+    float s = 0.f;
+    for (int k = threadIdx.x; k < K; k += 1024) {
+        const float v = __fadd_rn(__fmul_rn(cs[k], decay), __fmul_rn(one_minus, (float)counts[k]));   // torch: two products, one sum
+        cs[k] = v;
+        s += v;
+    }
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 512; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    const float n = red[0];
+    for (int k = threadIdx.x; k < K; k += 1024) cs[k] = __fmul_rn(__fdiv_rn(cs[k] + eps, n + keps), n);   // same thread wrote cs[k] above
+    __syncthreads();
+    const int total = K * E;
+    for (int t = threadIdx.x; t < total; t += 1024) {
+        const float w = __fadd_rn(__fmul_rn(ema_w[t], decay), __fmul_rn(one_minus, dw[t]));
+        ema_w[t] = w;
+        cb[t] = w / cs[t / E];
+    }
+}
+
+extern "C" int star_vq_code_sums(const float* x, const int64_t* idx, float* dw, float* ws, int M, int E, int K, void* stream) {
+    STAR_CHECK(x && idx && dw && ws, "star_vq_code_sums: null pointer (ws: star_vq_bwd_ws(M, E, K) floats)");
+    STAR_CHECK(M > 0 && K > 0 && E > 0, "star_vq_code_sums: bad shape M=%d K=%d E=%d", M, K, E);
+    hipStream_t s = (hipStream_t)stream;
+    int C, rp;
+    vq_bwd_plan(M, &C, &rp);
+    const int G = K >= 1024 ? 8 : 2;
+    const size_t lds = (size_t)4 * G * E * sizeof(float);
+    hipLaunchKernelGGL(vq_bwd_codes_kernel<true>, dim3(cdiv(K, 4 * G), C), dim3(256), lds, s, x, idx, (const float*)nullptr, ws, M, E, K, G, rp);
+    const int64_t n = (int64_t)K * E;
+    hipLaunchKernelGGL(vq_bwd_codes_reduce_kernel, dim3(cdiv(n, 256)), dim3(256), 0, s, ws, dw, n, C, 1.0f);
+    STAR_LAUNCH_CHECK("star_vq_code_sums");
+    return 0;
+}
+
+extern "C" int star_vq_ema_update(const int32_t* counts, const float* dw, float* codebook, float* ema_w, float* cluster_size, int E, int K,
+                                  double decay, double epsilon, void* stream) {
+    STAR_CHECK(counts && dw && codebook && ema_w && cluster_size, "star_vq_ema_update: null pointer");
+    STAR_CHECK(K > 0 && E > 0 && (int64_t)K * E < (1ll << 31), "star_vq_ema_update: bad shape K=%d E=%d", K, E);
+    STAR_CHECK(decay > 0.0 && decay < 1.0, "star_vq_ema_update: decay %g not in (0, 1)", decay);
+    hipLaunchKernelGGL(vq_ema_update_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, counts, dw, codebook, ema_w, cluster_size, E, K,
+                       (float)decay, (float)(1.0 - decay), (float)epsilon, (float)(K * epsilon));
+    STAR_LAUNCH_CHECK("star_vq_ema_update");
     return 0;
 }
 

@@ -43,6 +43,8 @@ class Config:
         vq = getattr(model, "_vq_star", None)                 # VQ-STAR variant (star/models/VQSTAR.py)
         self.vq = vq is not None
         self.commitment = float(vq._commitment_cost) if vq is not None else 0.0
+        self.vq_decay = float(getattr(vq, "_decay", 0.0)) if vq is not None else 0.0    # > 0: EMA codebook (mae_base.py:176)
+        self.vq_epsilon = float(getattr(vq, "_epsilon", 1e-5)) if vq is not None else 0.0
         self.grid = self.img // self.patch
         self.L = self.grid * self.grid
         self.V = self.chans * self.patch * self.patch
@@ -189,7 +191,7 @@ def stages(cfg):
     if not cfg.no_temp_emb:
         mid.append("decoder_temp_embed")
     mid += ["decoder_embed.weight", "decoder_embed.bias", "decompressor.weight", "decompressor.bias"]
-    if getattr(cfg, "vq", False):
+    if getattr(cfg, "vq", False) and not getattr(cfg, "vq_decay", 0.0) > 0.0:     # an EMA codebook is not a trained parameter
         mid.append("_vq_star._embedding.weight")
     mid += ["compressor.0.weight", "compressor.0.bias", "norm.weight", "norm.bias"]
     out.append(mid)
@@ -263,7 +265,8 @@ def _block_bwd(g, g_lp, s, P, W, dt, grads, G=None, side=None):
 
 
 # -------------------------------------------------------------------------------------------------------
-def forward(cfg, P, W, dt, imgs1, imgs_next, trans_matrices, num_agent, batch, mask_ratio, infer, train, noise=None, taps=None):
+def forward(cfg, P, W, dt, imgs1, imgs_next, trans_matrices, num_agent, batch, mask_ratio, infer, train, noise=None, taps=None,
+            vq_update=False):
     """Runs the model.  Returns (out, ctx): out = dict(loss [1], result, latent, ind); ctx feeds backward()."""
     dev = imgs1.device
     ba, c, hh, ww = imgs1.shape
@@ -317,10 +320,23 @@ def forward(cfg, P, W, dt, imgs1, imgs_next, trans_matrices, num_agent, batch, m
     vq = None
     dec_in_lp = latent_lp
     if cfg.vq:
-        vq = ops.vq_assign(latent, P["_vq_star._embedding.weight"], dt, want_f32=taps is not None)
+        codebook = P["_vq_star._embedding.weight"]
+        vq = ops.vq_assign(latent, codebook, dt, want_f32=taps is not None)
         dec_in_lp = vq["q_lp"]
         if taps is not None:
             taps["quantized"], taps["vq_indices"] = vq["q_f32"], vq["idx"]
+        if cfg.vq_decay > 0.0 and vq_update:
+            # EMA codebook (mae_base.py:228-241): the quantised rows above used the codebook BEFORE this update, and so
+            # does the backward pass (a copy is kept for it).  Data-parallel ranks pool their statistics first.
+            vq["codebook_used"] = codebook.detach().clone() if train else None
+            counts = vq["counts"]
+            dw = ops.vq_code_sums(latent, vq["idx"], codebook.shape[0])
+            if torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
+                counts = counts.clone()
+                torch.distributed.all_reduce(counts)
+                torch.distributed.all_reduce(dw)
+            ops.vq_ema_update(counts, dw, codebook.data, P["_vq_star._ema_w"].data, P["_vq_star._ema_cluster_size"], cfg.vq_decay,
+                              cfg.vq_epsilon)
 
     # ---- decoder ----------------------------------------------------------------------------------------------
     z, _, _ = ops.gemm(dec_in_lp, _lin(P, W, "decompressor", dt), bias=P["decompressor.bias"])
@@ -364,14 +380,16 @@ def forward(cfg, P, W, dt, imgs1, imgs_next, trans_matrices, num_agent, batch, m
     result = ops.warp_fuse(ce["ind8"], theta, na.contiguous(), batch, ego=imgs1 if infer else None, binary=True)
     out = dict(loss=ce["loss"], result=result, latent=latent.reshape(n_frames, keep, cfg.inter), ind=ce["ind64"], mask=mask)
     if cfg.vq:   # loss = vq_loss + recon_loss (VQSTAR.py:443); the sum is formed on the device, in stream order
-        stats = ops.vq_finish(vq["part"], vq["counts"], n_frames * keep, cfg.inter, cfg.commitment, loss_inout=ce["loss"])
+        stats = ops.vq_finish(vq["part"], vq["counts"], n_frames * keep, cfg.inter, cfg.commitment, loss_inout=ce["loss"],
+                              ema=cfg.vq_decay > 0.0)
         out.update(vq_loss=stats[0:1], perplexity=stats[1:2], vq_indices=vq["idx"])
     ctx = None
     if train:
         ctx = dict(save=save, a_pe=a_pe, channels_last=channels_last, src_row=src_row, dst_row=dst_row, fill=fill, x_enc=x,
                    mean_e=mean_e, rstd_e=rstd_e, y=y, latent_lp=latent_lp, z=z, xd=xd, mean_d=mean_d, rstd_d=rstd_d, yd=yd,
                    dlogits=ce["dlogits"], keep=keep, ba=ba, l_enc=l_enc, random_mode=random_mode, dec_in_lp=dec_in_lp,
-                   latent=latent if cfg.vq else None, vq_idx=vq["idx"] if cfg.vq else None)
+                   latent=latent if cfg.vq else None, vq_idx=vq["idx"] if cfg.vq else None,
+                   vq_codebook=vq.get("codebook_used") if cfg.vq else None)
     return out, ctx
 
 
@@ -432,8 +450,12 @@ def backward(cfg, P, W, dt, ctx, G=None, on_ready=None):
         # only sees the q_latent term (mae_base.py:162-166); then the compressor's ReLU
         dq, _, _ = ops.gemm(dz, _lin(P, W, "decompressor", dt, True))
         name = "_vq_star._embedding.weight"
-        dlat, dcb = ops.vq_bwd(dq, ctx["latent"], ctx["vq_idx"], P[name], cfg.commitment, dcodebook=None if G is None else G[name])
-        grads[name] = dcb
+        if cfg.vq_decay > 0.0:      # EMA codebook: no gradient to the codes; q is read from the codebook the forward used
+            used = ctx["vq_codebook"] if ctx["vq_codebook"] is not None else P[name]
+            dlat, _ = ops.vq_bwd(dq, ctx["latent"], ctx["vq_idx"], used, cfg.commitment, want_dcodebook=False)
+        else:
+            dlat, dcb = ops.vq_bwd(dq, ctx["latent"], ctx["vq_idx"], P[name], cfg.commitment, dcodebook=None if G is None else G[name])
+            grads[name] = dcb
     else:
         dlat, _, _ = ops.gemm(dz, _lin(P, W, "decompressor", dt, True), act=ACT_DRELU, aux=ctx["latent_lp"])
     comp_rows = None if cfg.encode_partial else ctx["src_row"]

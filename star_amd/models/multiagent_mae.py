@@ -109,7 +109,7 @@ class AmortizedIndivMMAEViT(MultiAgentMaskedAutoencoderViT):
         self.num_agent = imgs1.shape[0] // batch_size
         return dict(imgs1=imgs1.float(), imgs_next=imgs_next.float() if imgs_next.dim() > 2 else imgs_next,
                     trans_matrices=trans_matrices, num_agent=num_agent_tensor, batch=batch_size, mask_ratio=mask_ratio,
-                    infer=infer, noise=self._noise_override, taps=self._taps)
+                    infer=infer, noise=self._noise_override, taps=self._taps, vq_update=self.training)
 
     def _named_trainable(self):
         names, params = [], []
@@ -124,6 +124,7 @@ class AmortizedIndivMMAEViT(MultiAgentMaskedAutoencoderViT):
             names, params = self._named_trainable()
             return _StarFunction.apply(self, inputs, names, *params)
         P = {n: prm for n, prm in self.named_parameters()}
+        P.update(self._frozen_tables())
         out, _ = engine.forward(self._cfg(), P, self._weights, self._dt(), train=False, **inputs)
         return (out["loss"].reshape(()), out["result"], out["latent"], out["ind"]) + tuple(out[k] for k in _EXTRAS if k in out)
 

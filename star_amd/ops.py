@@ -420,11 +420,31 @@ def vq_assign(x, codebook, dt, want_f32=True, want_lp=True, want_stats=True):
     return dict(idx=idx, q_f32=q32, q_lp=qlp, part=part, counts=counts)
 
 
-def vq_finish(part, counts, m, e, commitment, loss_inout=None):
-    """-> float32 [3] = (vq loss, perplexity, mse); loss_inout[0] += vq loss."""
+def vq_finish(part, counts, m, e, commitment, loss_inout=None, ema=False):
+    """-> float32 [3] = (vq loss, perplexity, mse); loss_inout[0] += vq loss.  ema: loss = commitment * mse alone."""
     out = torch.empty(3, dtype=torch.float32, device=part.device)
-    L.check(L.lib().star_vq_finish(p(part), part.numel(), p(counts), m, e, counts.numel(), float(commitment), p(out), p(loss_inout), L.stream()))
+    L.check(L.lib().star_vq_finish(p(part), part.numel(), p(counts), m, e, counts.numel(), float(commitment), int(ema), p(out),
+                                   p(loss_inout), L.stream()))
     return out
+
+
+def vq_code_sums(x, idx, k):
+    """-> float32 [K,E]: per-code sums of the rows of x assigned to it (deterministic order)."""
+    m, e = x.shape
+    dw = torch.empty(k, e, dtype=torch.float32, device=x.device)
+    ws = torch.empty(L.lib().star_vq_bwd_ws(m, e, k), dtype=torch.float32, device=x.device)
+    with _timed("vq_code_sums", 0.0, float(m * e * 4 + m * 8 + k * e * 4)):
+        L.check(L.lib().star_vq_code_sums(p(x), p(idx), p(dw), p(ws), m, e, k, L.stream()))
+    return dw
+
+
+def vq_ema_update(counts, dw, codebook, ema_w, cluster_size, decay, epsilon=1e-5):
+    """In-place EMA update of (cluster_size [K], ema_w [K,E], codebook [K,E]) from this batch's counts int32 [K] and dw [K,E]."""
+    k, e = codebook.shape
+    for t in (dw, codebook, ema_w, cluster_size):
+        assert t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()
+    assert counts.dtype == torch.int32 and counts.numel() == k and tuple(dw.shape) == (k, e) == tuple(ema_w.shape) and cluster_size.numel() == k
+    L.check(L.lib().star_vq_ema_update(p(counts), p(dw), p(codebook), p(ema_w), p(cluster_size), e, k, float(decay), float(epsilon), L.stream()))
 
 
 def vq_bwd(dq, x, idx, codebook, commitment, want_dlat=True, dcodebook=None, want_dcodebook=True):

@@ -13,7 +13,7 @@ import torch
 import torch.nn as nn
 
 from golden_util import GOLD
-from vq_util import VQ_CASES, VQ_DIMS, VQCase
+from vq_util import VQ_CASES, VQ_DIMS, VQ_EMA_CASES, VQCase
 
 pytestmark = pytest.mark.gpu
 
@@ -96,9 +96,10 @@ def build(c, dtype):
     m = VQSTARViT(img_size=c.S, patch_size=d["patch"], in_chans=d["chans"], embed_dim=d["dim"], depth=d["depth"], num_heads=d["heads"],
                   decoder_embed_dim=d["ddim"], decoder_depth=d["ddepth"], decoder_num_heads=d["dheads"], mlp_ratio=4,
                   norm_layer=partial(nn.LayerNorm, eps=1e-6), time_stamp=c.T, mask_method=c.mask, commitment_cost=c.cc,
-                  num_vq_embeddings=c.K, vq_embedding_dim=c.E)
-    assert list(m.state_dict().keys()) == list(c.sd.keys())          # incl. _vq_star._embedding.weight, same order
+                  num_vq_embeddings=c.K, vq_embedding_dim=c.E, decay=c.decay)
+    assert list(m.state_dict().keys()) == list(c.sd.keys())          # incl. _vq_star._embedding.weight (+ EMA state), same order
     m.load_state_dict(c.sd)
+    m._vq_star.data_initialized = 1                                  # the EMA goldens start after the k-means seeding
     m = m.to(DEV).set_compute_dtype(dtype)
     m.train() if c.train else m.eval()
     m._noise_override = c.noise.to(DEV)
@@ -106,7 +107,7 @@ def build(c, dtype):
     return m
 
 
-@pytest.mark.parametrize("name", VQ_CASES)
+@pytest.mark.parametrize("name", VQ_CASES + VQ_EMA_CASES)
 def test_vq_model_against_golden_fp32(name):
     c = VQCase(name)
     m = build(c, "fp32")
@@ -140,6 +141,68 @@ def test_vq_model_against_golden_fp32(name):
                     assert params[k].grad is None, k
                 else:
                     torch.testing.assert_close(params[k].grad.cpu(), g, rtol=2e-3, atol=2e-6, msg=lambda s, k=k: k + ": " + s)
+        if c.decay > 0:      # EMA codebook: state after the step as the reference holds it (untouched in eval mode)
+            vq = m._vq_star
+            torch.testing.assert_close(vq._ema_cluster_size.cpu(), torch.from_numpy(c.z["post_cluster_size"]), rtol=1e-6, atol=1e-7)
+            torch.testing.assert_close(vq._ema_w.cpu(), torch.from_numpy(c.z["post_ema_w"]), rtol=1e-5, atol=1e-7)
+            torch.testing.assert_close(vq._embedding.weight.cpu(), torch.from_numpy(c.z["post_embedding"]), rtol=1e-5, atol=1e-7)
+            if not c.train:
+                assert torch.equal(vq._embedding.weight.cpu(), c.sd["_vq_star._embedding.weight"])
+
+
+def test_ema_update_kernels_against_oracle():
+    """star_vq_code_sums + star_vq_ema_update against the oracle's restatement of mae_base.py:228-241 at K = 8192, E = 32
+    and a ragged size; unused codes decay, the sums are deterministic."""
+    g = torch.Generator().manual_seed(1)
+    for m, k, e, decay in ((8192, 8192, 32, 0.99), (1000, 515, 64, 0.8)):
+        x = torch.relu(torch.randn(m, e, generator=g))
+        cb = (torch.randn(k, e, generator=g) * 0.5).abs()
+        cs = torch.rand(k, generator=g) * 3
+        w = cb * cs[:, None]
+        v = ops.vq_assign(x.to(DEV), cb.to(DEV), F32)
+        idx = v["idx"].cpu()
+        dw = ops.vq_code_sums(x.to(DEV), v["idx"], k)
+        assert torch.equal(dw, ops.vq_code_sums(x.to(DEV), v["idx"], k))
+        want = torch.zeros(k, e, dtype=torch.float64).index_add_(0, idx, x.double())
+        torch.testing.assert_close(dw.cpu().double(), want, rtol=1e-5, atol=1e-6)
+        # oracle on the kernel's own indices (near-ties may flip an index; the update itself is what is checked here)
+        enc = torch.zeros(m, k).scatter_(1, idx[:, None], 1)
+        ncs = cs * decay + (1 - decay) * enc.sum(0)
+        n = ncs.sum()
+        ncs = (ncs + 1e-5) / (n + k * 1e-5) * n
+        nw = w * decay + (1 - decay) * (enc.t() @ x)
+        d_cb, d_w, d_cs = cb.to(DEV), w.to(DEV), cs.to(DEV)
+        ops.vq_ema_update(v["counts"], dw, d_cb, d_w, d_cs, decay)
+        torch.testing.assert_close(d_cs.cpu(), ncs, rtol=1e-5, atol=1e-7)
+        torch.testing.assert_close(d_w.cpu(), nw, rtol=1e-5, atol=1e-6)
+        torch.testing.assert_close(d_cb.cpu(), nw / ncs[:, None], rtol=2e-5, atol=1e-6)
+
+
+def test_vqstar_ema_training_steps_full_model():
+    """decay > 0 through CoModule with the fused optimiser: the first training step seeds `_ema_w` by k-means (once), later
+    steps move the codebook without any optimizer state for it; eval-mode inference leaves it alone."""
+    torch.manual_seed(0)
+    model = vqstar(time_stamp=1, mask_method="complement", num_vq_embeddings=256, vq_embedding_dim=32, decay=0.99).to(DEV)
+    opt = FlatAdamW(model, lr=1e-3, betas=(0.9, 0.999), weight_decay=0.0, grouping="flat")
+    assert "_vq_star._embedding.weight" not in opt.offsets and "_vq_star._ema_w" not in opt.offsets
+    cm = CoModule(model, opt, "vqstar")
+    data = make_batch(1, 5, 1, seed=3, device=DEV)
+    model.train()
+    vq = model._vq_star
+    assert vq.data_initialized == 0
+    seen = []
+    for it in range(4):
+        loss, result, ind, perplexity = cm.step_vqstar_completion(data, 1, 0.75, trainable=True)
+        assert np.isfinite(loss) and float(perplexity) >= 1.0 and vq.data_initialized == 1
+        seen.append(vq._embedding.weight.detach().clone())
+        assert torch.isfinite(seen[-1]).all() and float(vq._ema_cluster_size.sum()) > 0
+    assert not torch.equal(seen[0], seen[-1])
+    model.eval()
+    cm.infer_vqstar_completion(data, 1, 0.75)
+    assert torch.equal(vq._embedding.weight.detach(), seen[-1])
+    sd = opt.state_dict()                         # one group over model.parameters(), the EMA tensors included (no state for them)
+    assert len(sd["param_groups"][0]["params"]) == len(list(model.parameters()))
+
 
 
 def test_vqstar_training_step_full_size_bf16():
