@@ -8,6 +8,7 @@
 #define LN_THREADS 256
 #define LN_MAXV 8          // float4 per lane: D <= 64*4*8 = 2048
 #define LN_BWD_BLOCKS 1024  // partial dgamma/dbeta rows
+#define LN_BWD_THREADS 512  // 8 waves: 1024 blocks put 8 waves on every SIMD, each with one row's loads in flight
 
 template <typename T, int NV>
 __global__ __launch_bounds__(LN_THREADS) void ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
@@ -63,15 +64,17 @@ __global__ __launch_bounds__(LN_THREADS) void ln_fwd_kernel(const float* __restr
 }
 
 // Backward.  Each wave walks rows with a grid stride and keeps its dgamma/dbeta partials in registers;
-// the block folds its 4 waves through LDS and writes one partial row; a second kernel sums the partial
-// rows in a fixed order (deterministic).
+// the block folds its waves through LDS and writes one partial row; a second kernel sums the partial
+// rows in a fixed order (deterministic).  All three inputs of a row (x, dy and the incoming residual gradient) are
+// requested before the first reduction, so a row costs ONE memory latency (g_in may alias g_out: same row, read first).
 template <typename T, int NV>
-__global__ __launch_bounds__(LN_THREADS) void ln_bwd_kernel(const T* __restrict__ dy, const float* __restrict__ x,
+__global__ __launch_bounds__(LN_BWD_THREADS) void ln_bwd_kernel(const T* __restrict__ dy, const float* __restrict__ x,
                                                             const float* __restrict__ gamma, const float* __restrict__ mean,
                                                             const float* __restrict__ rstd, const float* g_in,
                                                             float* g_out, T* __restrict__ g_lp,
                                                             float* __restrict__ ws, int M, int D) {
-    extern __shared__ float s_part[];  // [4 waves][2][D]
+    extern __shared__ float s_part[];  // [waves][2][D]
+    constexpr int NW = LN_BWD_THREADS / 64;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nv = D >> 2;
     float pg[NV][4], pb[NV][4], gm[NV][4];
@@ -82,10 +85,17 @@ __global__ __launch_bounds__(LN_THREADS) void ln_bwd_kernel(const T* __restrict_
         for (int k = 0; k < 4; ++k) pg[i][k] = pb[i][k] = 0.f;
         if (c < nv) ld4(gamma + c * 4, gm[i]);
     }
-    for (int row = blockIdx.x * 4 + wave; row < M; row += gridDim.x * 4) {
+    for (int row = blockIdx.x * NW + wave; row < M; row += gridDim.x * NW) {
         const float mu = mean[row], rs = rstd[row];
-        float xh[NV][4], dg[NV][4];
+        float xh[NV][4], dg[NV][4], gi[NV][4];
         float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = lane + i * 64;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) gi[i][k] = 0.f;
+            if (g_in && c < nv) ld4(g_in + (size_t)row * D + c * 4, gi[i]);
+        }
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             const int c = lane + i * 64;
@@ -113,10 +123,8 @@ __global__ __launch_bounds__(LN_THREADS) void ln_bwd_kernel(const T* __restrict_
 #pragma unroll
                 for (int k = 0; k < 4; ++k) o[k] = rs * (dg[i][k] - m1 - xh[i][k] * m2);
                 if (g_in) {
-                    float gi[4];
-                    ld4(g_in + (size_t)row * D + c * 4, gi);
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) o[k] += gi[k];
+                    for (int k = 0; k < 4; ++k) o[k] += gi[i][k];
                 }
                 if (g_out) st4(g_out + (size_t)row * D + c * 4, o);
                 if (g_lp) st4(g_lp + (size_t)row * D + c * 4, o);
@@ -132,11 +140,11 @@ __global__ __launch_bounds__(LN_THREADS) void ln_bwd_kernel(const T* __restrict_
         }
     }
     __syncthreads();
-    for (int e = threadIdx.x; e < 2 * D; e += LN_THREADS) {
+    for (int e = threadIdx.x; e < 2 * D; e += LN_BWD_THREADS) {
         const int which = e / D, c = e - which * D;
         float a = 0.f;
 #pragma unroll
-        for (int w = 0; w < 4; ++w) a += s_part[(size_t)(w * 2 + which) * D + c];
+        for (int w = 0; w < NW; ++w) a += s_part[(size_t)(w * 2 + which) * D + c];
         ws[(size_t)blockIdx.x * 2 * D + e] = a;
     }
 }
@@ -200,16 +208,22 @@ extern "C" int star_layernorm_bwd(const void* dy, const float* x, const float* g
                                   float* dbeta, float* ws, int M, int D, int dt, void* stream) {
     STAR_CHECK(dy && x && gamma && mean && rstd && ws, "star_layernorm_bwd: null pointer");
     STAR_CHECK(M > 0 && D >= 4 && D % 4 == 0 && D <= 64 * 4 * LN_MAXV, "star_layernorm_bwd: bad M=%d D=%d", M, D);
-    int nb = cdiv(M, 4);
+    int nb = cdiv(M, LN_BWD_THREADS / 64);
     if (nb > LN_BWD_BLOCKS) nb = LN_BWD_BLOCKS;
-    const size_t lds = (size_t)8 * D * sizeof(float);
+    const size_t lds = (size_t)(LN_BWD_THREADS / 64) * 2 * D * sizeof(float);
 #define LN_BWD(NV)                                                                                                   \
     do {                                                                                                             \
+        if (lds > 64 * 1024) {   /* D > 1024: more dynamic LDS than the default limit */                              \
+            const hipError_t ea = dt == STAR_BF16                                                                    \
+                ? hipFuncSetAttribute((const void*)ln_bwd_kernel<bf16_t, NV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) \
+                : hipFuncSetAttribute((const void*)ln_bwd_kernel<float, NV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+            if (ea != hipSuccess) return star_set_error(-2, "star_layernorm_bwd: LDS attribute: %s", hipGetErrorString(ea)); \
+        }                                                                                                            \
         if (dt == STAR_BF16)                                                                                         \
-            hipLaunchKernelGGL((ln_bwd_kernel<bf16_t, NV>), dim3(nb), dim3(LN_THREADS), lds, (hipStream_t)stream,      \
+            hipLaunchKernelGGL((ln_bwd_kernel<bf16_t, NV>), dim3(nb), dim3(LN_BWD_THREADS), lds, (hipStream_t)stream,      \
                                (const bf16_t*)dy, x, gamma, mean, rstd, g_in, g_out, (bf16_t*)g_out_lp, ws, M, D);   \
         else                                                                                                         \
-            hipLaunchKernelGGL((ln_bwd_kernel<float, NV>), dim3(nb), dim3(LN_THREADS), lds, (hipStream_t)stream,       \
+            hipLaunchKernelGGL((ln_bwd_kernel<float, NV>), dim3(nb), dim3(LN_BWD_THREADS), lds, (hipStream_t)stream,       \
                                (const float*)dy, x, gamma, mean, rstd, g_in, g_out, (float*)g_out_lp, ws, M, D);     \
     } while (0)
     const int nvec = (D / 4 + 63) / 64;
