@@ -180,7 +180,7 @@ int star_gather_rows(const float* src, const int32_t* rows, float* dst_f32, void
 int star_scatter_rows(const void* src, int src_dt, const int32_t* rows, float* dst, int M, int D, void* stream);
 /* Grouped column sums: out[g, :] = sum over rows r with (r / div) % mod == g and (sel == NULL or
  * sel[r] matches want) of src[r, :].  src in `dt` (STAR_F32 reads float32).  Used for the gradients of
- * decoder_temp_embed, mask_token and the patch-embedding bias.  ws float32 [64 * mod * D]. */
+ * decoder_temp_embed, mask_token and the patch-embedding bias.  D % 4 == 0; ws float32 [64 * mod * D]. */
 int star_colsum_groups(const void* src, int dt, const int32_t* sel, int sel_nonneg, int R, int D, int div, int mod, float* ws,
                        float* out, void* stream);
 /* dst[c, r] = cast(src[r, c]): the transposed low-precision copy of a weight used by the dX GEMMs. */

@@ -55,27 +55,46 @@ extern "C" int star_scatter_rows(const void* src, int src_dt, const int32_t* row
     return 0;
 }
 
-// block = 64 columns x 4 row lanes; grid (column chunks, groups, row splits); fixed-order second stage
+// block = 256 columns (4 per lane) x 16 row lanes (waves); grid (column chunks, groups, row splits); every wave keeps eight
+// row loads in flight; fixed-order folds (waves through LDS, then the second stage) -> deterministic
 template <typename T>
-__global__ __launch_bounds__(256) void colsum_groups_kernel(const T* __restrict__ src, const int32_t* __restrict__ sel, int sel_nonneg,
-                                                            float* __restrict__ part, int R, int D, int div, int mod, int rows_per) {
-    __shared__ float s[4][64];
-    const int c = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
+__global__ __launch_bounds__(1024) void colsum_groups_kernel(const T* __restrict__ src, const int32_t* __restrict__ sel, int sel_nonneg,
+                                                             float* __restrict__ part, int R, int D, int div, int mod, int rows_per) {
+    __shared__ float s[16][256];
+    const int lane = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int c = blockIdx.x * 256 + lane * 4;
     const int grp = blockIdx.y;
     const int r0 = blockIdx.z * rows_per, r1 = min(R, r0 + rows_per);
-    float a = 0.f;
-    if (c < D)
-        for (int r = r0 + rl; r < r1; r += 4) {
-            if ((r / div) % mod != grp) continue;
-            if (sel) {
-                const int sv = sel[r];
-                if (sel_nonneg ? (sv < 0) : (sv == 0)) continue;
+    float a[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int r = r0 + rl; r < r1; r += 16 * 8) {
+        float v[8][4];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int rr = r + u * 16;
+            bool ok = c < D && rr < r1 && (rr / div) % mod == grp;
+            if (ok && sel) {
+                const int sv = sel[rr];
+                ok = sel_nonneg ? sv >= 0 : sv != 0;
             }
-            a += Act<T>::ld(src + (size_t)r * D + c);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[u][k] = 0.f;
+            if (ok) ld4(src + (size_t)rr * D + c, v[u]);
         }
-    s[rl][threadIdx.x & 63] = a;
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) a[k] += v[u][k];
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) s[rl][lane * 4 + k] = a[k];
     __syncthreads();
-    if (rl == 0 && c < D) part[((size_t)blockIdx.z * mod + grp) * D + c] = (s[0][threadIdx.x] + s[1][threadIdx.x]) + (s[2][threadIdx.x] + s[3][threadIdx.x]);
+    const int t = threadIdx.x, col = blockIdx.x * 256 + t;
+    if (t < 256 && col < D) {
+        float f = 0.f;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) f += s[w][t];
+        part[((size_t)blockIdx.z * mod + grp) * D + col] = f;
+    }
 }
 __global__ void colsum_groups_reduce_kernel(const float* __restrict__ part, float* __restrict__ out, int n, int S) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
@@ -87,15 +106,15 @@ __global__ void colsum_groups_reduce_kernel(const float* __restrict__ part, floa
 
 extern "C" int star_colsum_groups(const void* src, int dt, const int32_t* sel, int sel_nonneg, int R, int D, int div, int mod, float* ws,
                                   float* out, void* stream) {
-    STAR_CHECK(src && ws && out && R > 0 && D > 0 && div > 0 && mod > 0 && mod <= 65535, "star_colsum_groups: bad arguments");
-    int S = cdiv(R, 1024);
+    STAR_CHECK(src && ws && out && R > 0 && D > 0 && D % 4 == 0 && div > 0 && mod > 0 && mod <= 65535, "star_colsum_groups: bad arguments (D %% 4 == 0)");
+    int S = cdiv(R, 256);
     if (S > 64) S = 64;
     const int rows_per = cdiv(R, S);
-    dim3 grid(cdiv(D, 64), mod, S);
+    dim3 grid(cdiv(D, 256), mod, S);
     if (dt == STAR_BF16)
-        hipLaunchKernelGGL(colsum_groups_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)src, sel, sel_nonneg, ws, R, D, div, mod, rows_per);
+        hipLaunchKernelGGL(colsum_groups_kernel<bf16_t>, grid, dim3(1024), 0, (hipStream_t)stream, (const bf16_t*)src, sel, sel_nonneg, ws, R, D, div, mod, rows_per);
     else
-        hipLaunchKernelGGL(colsum_groups_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)src, sel, sel_nonneg, ws, R, D, div, mod, rows_per);
+        hipLaunchKernelGGL(colsum_groups_kernel<float>, grid, dim3(1024), 0, (hipStream_t)stream, (const float*)src, sel, sel_nonneg, ws, R, D, div, mod, rows_per);
     STAR_LAUNCH_CHECK("star_colsum_groups");
     hipLaunchKernelGGL(colsum_groups_reduce_kernel, dim3(cdiv((int64_t)mod * D, 256)), dim3(256), 0, (hipStream_t)stream, ws, out, mod * D, S);
     STAR_LAUNCH_CHECK("star_colsum_groups(reduce)");

@@ -477,3 +477,23 @@ def test_warp_fuse_edge_cases_vs_oracle():
     got = out.cpu().numpy().reshape(A, B, C, S, S)
     assert set(np.unique(got)) <= {0.0, 1.0}
     assert (got[0, 0] >= x[0, 0]).all() and (got[0, 0] <= np.maximum(x[0, 0], x[2, 0])).all()   # agent 1's NaN pose contributes nothing to ego 0
+
+
+@pytest.mark.parametrize("dt", ["bf16", "fp32"])
+def test_colsum_groups_vs_torch(dt):
+    """Grouped column sums (gradients of decoder_temp_embed / mask_token): ragged row counts, widths that do not fill a
+    256-column block, time groups, both selector conventions; float64 torch sums of the same (rounded) values."""
+    g = torch.Generator().manual_seed(5)
+    for R, D, div, mod in ((40960, 256, 1024, 1), (3000, 132, 100, 3), (77, 384, 5, 2), (5000, 512, 1, 1)):
+        src = torch.randn(R, D, generator=g)
+        src = src.bfloat16() if dt == "bf16" else src
+        sel = torch.randint(-1, 2, (R,), generator=g, dtype=torch.int32)
+        grp = (torch.arange(R) // div) % mod
+        for sel_t, nonneg in ((None, False), (sel, False), (sel, True)):
+            keep = torch.ones(R, dtype=torch.bool) if sel_t is None else (sel >= 0 if nonneg else sel != 0)
+            want = torch.zeros(mod, D, dtype=torch.float64)
+            want.index_add_(0, grp[keep], src.double()[keep])
+            got = ops.colsum_groups(src.to(DEV), div, mod, sel=None if sel_t is None else sel_t.to(DEV), sel_nonneg=nonneg)
+            torch.testing.assert_close(got.cpu().double(), want, rtol=1e-5, atol=1e-3)
+            again = ops.colsum_groups(src.to(DEV), div, mod, sel=None if sel_t is None else sel_t.to(DEV), sel_nonneg=nonneg)
+            assert torch.equal(got, again)
