@@ -442,6 +442,48 @@ __global__ void attn_delta_kernel(const T* __restrict__ out, const T* __restrict
 }
 
 
+// bf16 path of the same, coalesced on both sides: a block takes 64 consecutive rows of one sequence, reads them as they lie
+// in memory (a thread = one (row, head) = HD bf16 of O and dO in 16-byte loads, all in flight), transposes the sums through
+// LDS and writes [head][row] runs of 256 bytes (the per-thread version scattered 4-byte stores L*4 bytes apart).
+template <int HD>
+__global__ __launch_bounds__(256) void attn_delta_bf16_kernel(const bf16_t* __restrict__ out, const bf16_t* __restrict__ dout,
+                                                              const float* __restrict__ lse, float* __restrict__ ws, int NB, int L, int H,
+                                                              float inv_c) {
+    extern __shared__ float dl_tile[];   // [H][65]
+    const int blocks_per_seq = (L + 63) / 64;
+    const int nb = blockIdx.x / blocks_per_seq, l0 = (blockIdx.x % blocks_per_seq) * 64;
+    const int rows = min(64, L - l0);
+    const int64_t total = (int64_t)NB * L * H;
+    for (int i = threadIdx.x; i < rows * H; i += 256) {
+        const int r = i / H, h = i - r * H;
+        const int64_t base = ((int64_t)nb * L + l0 + r) * H * HD + h * HD;
+        uint4 a[HD / 8], b[HD / 8];
+#pragma unroll
+        for (int j = 0; j < HD / 8; ++j) {
+            a[j] = *reinterpret_cast<const uint4*>(out + base + j * 8);
+            b[j] = *reinterpret_cast<const uint4*>(dout + base + j * 8);
+        }
+        float sum = 0.f;
+#pragma unroll
+        for (int j = 0; j < HD / 8; ++j) {
+            const unsigned x[4] = {a[j].x, a[j].y, a[j].z, a[j].w}, y[4] = {b[j].x, b[j].y, b[j].z, b[j].w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                sum += __uint_as_float(x[k] << 16) * __uint_as_float(y[k] << 16) +
+                       __uint_as_float(x[k] & 0xffff0000u) * __uint_as_float(y[k] & 0xffff0000u);
+        }
+        dl_tile[h * 65 + r] = sum;
+    }
+    __syncthreads();
+    for (int j = threadIdx.x; j < H * 64; j += 256) {
+        const int h = j >> 6, r = j & 63;
+        if (r >= rows) continue;
+        const int64_t o = ((int64_t)nb * H + h) * L + l0 + r;
+        ws[o] = -dl_tile[h * 65 + r];
+        ws[total + o] = -lse[o] * inv_c;
+    }
+}
+
 // dQ: query on the lane (the forward's skeleton and ring).  Stage = K image | V image; K is read by rows for S
 // and transposed for dQ^T += K^T dS^T from the same image.  Keys past L need no mask: their K rows are zero.
 template <int HD>
@@ -943,7 +985,11 @@ extern "C" int star_attn_bwd(const void* qkv, const void* out, const void* dout,
     const int64_t items = (int64_t)NB * L * H;
     int rc = 0;
     if (dt == STAR_BF16) {
-        hipLaunchKernelGGL((attn_delta_kernel<bf16_t, true>), dim3(cdiv(items, 256)), dim3(256), 0, s, (const bf16_t*)out, (const bf16_t*)dout, lse, delta, NB, L, H, hd, 1.0f / c);
+        const dim3 dgrid(NB * cdiv(L, 64));
+        const size_t dlds = (size_t)H * 65 * sizeof(float);
+        if (hd == 16) hipLaunchKernelGGL(attn_delta_bf16_kernel<16>, dgrid, dim3(256), dlds, s, (const bf16_t*)out, (const bf16_t*)dout, lse, delta, NB, L, H, 1.0f / c);
+        else if (hd == 32) hipLaunchKernelGGL(attn_delta_bf16_kernel<32>, dgrid, dim3(256), dlds, s, (const bf16_t*)out, (const bf16_t*)dout, lse, delta, NB, L, H, 1.0f / c);
+        else hipLaunchKernelGGL(attn_delta_bf16_kernel<64>, dgrid, dim3(256), dlds, s, (const bf16_t*)out, (const bf16_t*)dout, lse, delta, NB, L, H, 1.0f / c);
         STAR_LAUNCH_CHECK("star_attn_bwd(delta)");
         if (hd == 16) rc = bwd_bf16<16>(qkv, dout, lse, delta, dqkv, NB, L, H, c, scale, s);
         else if (hd == 32) rc = bwd_bf16<32>(qkv, dout, lse, delta, dqkv, NB, L, H, c, scale, s);
