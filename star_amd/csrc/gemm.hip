@@ -696,9 +696,168 @@ static void launch_nt_fast_epi(const StarGemm* g, hipStream_t s) {
         default: launch_nt_fast_geo<NST, EPI, 2, 2, 4>(g, s); break;
     }
 }
+// ------------------------------------------------------------------------------------------------------
+// W-in-registers NT GEMM for K = 32 NK <= 384 (plain Linear, bf16 output).  What bounds the tiled kernel above at small K
+// is operand traffic through LDS: per MFMA it moves 512 B of fragment reads plus 256 B of LDS-DMA writes, and re-fetches
+// the W panel for every tile.  Here a workgroup owns ONE 64 WN-column panel for its whole life: each consumer wave keeps
+// its 64 columns of W (all of K) in registers (4 x NK fragments = 16 NK VGPRs), so only A passes through LDS -- 256 B of
+// reads + 64 B of DMA per MFMA -- and L2 sees W once per workgroup.  One wave per SIMD (~330 VGPRs): WN consumer waves
+// plus a PRODUCER wave that does nothing but LDS-DMA (its vmcnt sees no stores, so the ring stays counted across tiles
+// and the consumers' epilogue stores never have to be drained).  One s_barrier per 32-deep stage; consumers read stage
+// s + 1 into a second fragment set before the MFMAs of stage s; a ring slot is refilled two barriers after its reads.
+template <int NK, int WN, int RB>
+__global__ __launch_bounds__((WN + 1) * 64) __attribute__((amdgpu_waves_per_eu(1, 1)))
+void gemm_nt_wreg_kernel(const StarGemm g, int row_tiles) {
+    constexpr int BM = RB * 16, NP = RB, NST = 8, PF = NST - 2, STAGE = BM * 64, K = NK * 32;   // a deeper ring (vmcnt up to 60) measured slower
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int N = g.N;
+    const int panels = N / (WN * 64);
+    const int q = xcd_remap(blockIdx.x, gridDim.x);
+    const int panel = q % panels, j0 = q / panels, J = (int)gridDim.x / panels;
+    const int my_tiles = j0 < row_tiles ? (row_tiles - j0 + J - 1) / J : 0;
+    const int total = my_tiles * NK;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (wave == WN) {
+        // ---- producer: stage s = (tile s / NK, k-step s % NK) = 64 rows x 64 B, four 16-row pieces
+        __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g.A), 0, 0x7fffffff, 0x00020000);
+        unsigned off[8];
+        static_assert(NP <= 8, "piece table");
+#pragma unroll
+        for (int j = 0; j < NP; ++j) {
+            const int r = j * 16 + (lane >> 2);
+            off[j] = (unsigned)(r * K * 2 + (((lane & 3) ^ ntf_swz(r)) << 4));
+        }
+        auto issue = [&](int st_) {
+            const int tl = st_ / NK, kt = st_ - tl * NK;
+            const unsigned base = (unsigned)((j0 + tl * J) * BM) * (unsigned)(K * 2) + (unsigned)(kt * 64);
+            unsigned char* dst = smem + (st_ % NST) * STAGE;
+#pragma unroll
+            for (int j = 0; j < NP; ++j)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (__attribute__((address_space(3))) void*)(dst + j * 16 * 64), 16, off[j] + base, 0, 0, 0);
+        };
+        for (int s0 = 0; s0 < PF && s0 < total; ++s0) issue(s0);
+        for (int st = 0; st < total; ++st) {
+            const int rem = min(total - 1 - st, PF - 1);
+            switch (rem * NP) {   // the asm needs immediates: every multiple of 4 up to 60 (vmcnt holds 63)
+#define WREG_VM(n) case n: asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory"); break;
+                WREG_VM(60) WREG_VM(56) WREG_VM(52) WREG_VM(48) WREG_VM(44) WREG_VM(40) WREG_VM(36) WREG_VM(32) WREG_VM(28) WREG_VM(24)
+                WREG_VM(20) WREG_VM(16) WREG_VM(12) WREG_VM(8) WREG_VM(4)
+#undef WREG_VM
+                default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+            }
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            if (st + PF < total) issue(st + PF);
+        }
+        return;
+    }
+    // ---- consumers
+    const int lr = lane & 15, lg = lane >> 4;
+    const int n_blk = panel * (WN * 64) + wave * 64;
+    const bf16_t* W = (const bf16_t*)g.W;
+    short8_t wreg[4][NK];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        const int n = n_blk + ntf_run_off<8>((lr >> 2) & 3, a) + (lr & 3);
+        const bf16_t* src = W + (size_t)n * K + lg * 8;
+#pragma unroll
+        for (int kt = 0; kt < NK; ++kt) wreg[a][kt] = *reinterpret_cast<const short8_t*>(src + kt * 32);
+    }
+    int fx[RB];
+#pragma unroll
+    for (int b = 0; b < RB; ++b) {
+        const int rx_ = b * 16 + lr;
+        fx[b] = rx_ * 64 + ((lg ^ ntf_swz(rx_)) << 4);
+    }
+    int roff[4];
+    float bias16[16];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) roff[a] = n_blk + ntf_run_off<8>(lg, a);
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (g.bias) t = *reinterpret_cast<const float4*>(g.bias + roff[a]);
+        bias16[4 * a] = t.x; bias16[4 * a + 1] = t.y; bias16[4 * a + 2] = t.z; bias16[4 * a + 3] = t.w;
+    }
+    bf16_t* out_lp = (bf16_t*)g.out_lp;
+    int st = 0;
+    for (int tile = 0; tile < my_tiles; ++tile) {
+        const int m_blk = (j0 + tile * J) * BM;
+        f32x4_t acc[4][RB];
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < RB; ++b) acc[a][b] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        short8_t x8[2][RB];
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        {
+            const unsigned char* sp = smem + (st % NST) * STAGE;
+#pragma unroll
+            for (int b = 0; b < RB; ++b) x8[0][b] = *reinterpret_cast<const short8_t*>(sp + fx[b]);
+        }
+#pragma unroll
+        for (int kt = 0; kt < NK; ++kt) {
+            if (kt + 1 < NK) {
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+                const unsigned char* sp = smem + ((st + kt + 1) % NST) * STAGE;
+#pragma unroll
+                for (int b = 0; b < RB; ++b) x8[(kt + 1) & 1][b] = *reinterpret_cast<const short8_t*>(sp + fx[b]);
+            }
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < RB; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wreg[a][kt]),
+                                                                        __builtin_bit_cast(bf16x8_t, x8[kt & 1][b]), acc[a][b], 0, 0, 0);
+        }
+        st += NK;
+        // epilogue: bias, bf16, two 16-byte stores per row (a row's four lanes write one contiguous 64-byte segment each)
+#pragma unroll
+        for (int b = 0; b < RB; ++b) {
+            bf16_t* row = out_lp + (size_t)(m_blk + b * 16 + lr) * N;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                float v[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = acc[2 * h + (e >> 2)][b][e & 3] + bias16[8 * h + e];
+                *reinterpret_cast<uint4*>(row + roff[2 * h]) = make_uint4(pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]), pack_bf16(v[4], v[5]), pack_bf16(v[6], v[7]));
+            }
+        }
+    }
+}
+
+// eligibility + launch of the W-in-registers kernel; returns false when the shape / epilogue is not covered.
+// Measured alone on MI355X at M = 40 960, K = 384 against the 256 x 128 tile: N = 1152 47.5 vs 53.8 us, N = 1536 62.5 vs
+// 74.2 us, N = 384 23.2 vs 22.0 us -> used from N = 1152 up.  STAR_AMD_GEMM_WREG=0 turns it off, =1 takes every eligible shape.
+static bool launch_nt_wreg(const StarGemm* g, hipStream_t s) {
+    static const char* env = getenv("STAR_AMD_GEMM_WREG");
+    if (env && env[0] == '0') return false;
+    constexpr int RB = 8, BM = RB * 16, LDS = 8 * BM * 64;
+    if (g->K != 384 || g->N % 192 != 0 || g->M % BM != 0 || g->a_rows || g->c_rows || g->out_f32 || !g->out_lp) return false;
+    if (!(env && env[0] == '1') && g->N < 1152) return false;
+    if ((long long)g->M * g->K * 2 >= 0x7fffffffLL) return false;
+    const int panels = g->N / 192;
+    int l = panels;
+    while (l % 8 != 0) l += panels;            // lcm(8, panels): whole panels per workgroup, whole workgroup sets per XCD
+    const int cus = star_num_cus();
+    if (l > cus) return false;
+    const int grid = cus / l * l;
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_wreg_kernel<12, 3, RB>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        attr = true;
+    }
+    hipLaunchKernelGGL((gemm_nt_wreg_kernel<12, 3, RB>), dim3(grid), dim3(256), (size_t)LDS, s, *g, g->M / BM);
+    return true;
+}
+
 template <int NST>
 static int launch_nt_fast(const StarGemm* g, hipStream_t s) {
     const bool plain = !g->res2 && !g->aux && !g->pre && g->act == STAR_ACT_NONE;
+    if (plain && !g->res && launch_nt_wreg(g, s)) return 0;
     if (plain && !g->res) launch_nt_fast_epi<NST, EPI_LINEAR>(g, s);
     else if (plain) launch_nt_fast_epi<NST, EPI_RES>(g, s);
     else if (g->act == STAR_ACT_GELU && g->pre && (g->flags & STAR_GEMM_PRE_IS_GRAD) && !g->res && !g->res2) launch_nt_fast_epi<NST, EPI_GELU_GRAD>(g, s);

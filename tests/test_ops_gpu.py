@@ -497,3 +497,24 @@ def test_colsum_groups_vs_torch(dt):
             torch.testing.assert_close(got.cpu().double(), want, rtol=1e-5, atol=1e-3)
             again = ops.colsum_groups(src.to(DEV), div, mod, sel=None if sel_t is None else sel_t.to(DEV), sel_nonneg=nonneg)
             assert torch.equal(got, again)
+
+
+@pytest.mark.parametrize("M,N", [(128, 1152), (128 * 33, 1536), (128 * 321, 1152), (40960, 2304)])
+def test_gemm_w_in_registers_path(M, N):
+    """Plain Linear with a bf16 output at K = 384, N % 192 == 0, M % 128 == 0, N >= 1152 takes the W-in-registers kernel
+    (producer wave + W fragments resident in VGPRs): fewer row tiles than workgroups, uneven tiles per workgroup, the
+    benched size; with and without bias; an identity A against an asymmetric W catches a wrong fragment or column map."""
+    g = torch.Generator().manual_seed(M + N)
+    K = 384
+    a, w = _rand_lp((M, K), g, 0), _rand_lp((N, K), g, 0, K ** -0.5)
+    bias = torch.randn(N, generator=g).to(DEV)
+    ref = a.double() @ w.double().t()
+    for b in (bias, None):
+        lp, f32, _ = ops.gemm(a, w, bias=b, want_lp=True, want_f32=False)
+        assert f32 is None
+        torch.testing.assert_close(lp.double(), ref + (0 if b is None else b.double()), **_tol(0))
+    eye = torch.zeros(M, K, device=DEV, dtype=torch.bfloat16)
+    idx = torch.arange(M, device=DEV)
+    eye[idx, idx % K] = 1
+    lp, _, _ = ops.gemm(eye, w, want_lp=True, want_f32=False)
+    assert torch.equal(lp, w.t()[idx % K])
