@@ -705,6 +705,10 @@ static void launch_nt_fast_epi(const StarGemm* g, hipStream_t s) {
 // plus a PRODUCER wave that does nothing but LDS-DMA (its vmcnt sees no stores, so the ring stays counted across tiles
 // and the consumers' epilogue stores never have to be drained).  One s_barrier per 32-deep stage; consumers read stage
 // s + 1 into a second fragment set before the MFMAs of stage s; a ring slot is refilled two barriers after its reads.
+// Measured variants that did not help (qkv shape, 47 us): 128-byte stage rows so that every LDS-DMA lane group fetches a
+// whole line (48 us); a 15-stage ring, vmcnt up to 60 (61 us at 64-row tiles); 64-row tiles (52 us).  With the MFMAs
+// compiled out the kernel still takes 36 us (one producer wave lands a 1 KiB piece every ~94 cycles = 11 B/clk/CU), with
+// the stores compiled out 37 us: the remaining lever is hiding the epilogue of tile t in the MFMA gaps of tile t + 1.
 template <int NK, int WN, int RB>
 __global__ __launch_bounds__((WN + 1) * 64) __attribute__((amdgpu_waves_per_eu(1, 1)))
 void gemm_nt_wreg_kernel(const StarGemm g, int row_tiles) {
