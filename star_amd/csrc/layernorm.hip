@@ -149,29 +149,30 @@ __global__ __launch_bounds__(LN_BWD_THREADS) void ln_bwd_kernel(const T* __restr
     }
 }
 
-// second stage: block = 64 columns x 16 row lanes over the partial rows, fixed order -> deterministic
+// second stage: block = 16 columns x 64 row lanes over the partial rows (48 blocks at D = 384 instead of 12: the kernel is
+// a latency chain per block), four independent accumulators per lane, fixed order -> deterministic
 __global__ __launch_bounds__(1024) void ln_bwd_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dgamma,
                                                              float* __restrict__ dbeta, int nblocks, int D) {
-    __shared__ float s[16][64];
-    const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
-    const int e = blockIdx.x * 64 + cl;
+    __shared__ float s[64][17];
+    const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
+    const int e = blockIdx.x * 16 + cl;
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
     if (e < 2 * D) {
         int b = rl;
-        for (; b + 48 < nblocks; b += 64) {
+        for (; b + 192 < nblocks; b += 256) {
             a0 += ws[(size_t)b * 2 * D + e];
-            a1 += ws[(size_t)(b + 16) * 2 * D + e];
-            a2 += ws[(size_t)(b + 32) * 2 * D + e];
-            a3 += ws[(size_t)(b + 48) * 2 * D + e];
+            a1 += ws[(size_t)(b + 64) * 2 * D + e];
+            a2 += ws[(size_t)(b + 128) * 2 * D + e];
+            a3 += ws[(size_t)(b + 192) * 2 * D + e];
         }
-        for (; b < nblocks; b += 16) a0 += ws[(size_t)b * 2 * D + e];
+        for (; b < nblocks; b += 64) a0 += ws[(size_t)b * 2 * D + e];
     }
     s[rl][cl] = (a0 + a1) + (a2 + a3);
     __syncthreads();
     if (rl == 0 && e < 2 * D) {
         float a = 0.f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) a += s[r][cl];
+        for (int r = 0; r < 64; ++r) a += s[r][cl];
         if (e < D) {
             if (dgamma) dgamma[e] = a;
         } else if (dbeta) {
@@ -229,7 +230,7 @@ extern "C" int star_layernorm_bwd(const void* dy, const float* x, const float* g
     const int nvec = (D / 4 + 63) / 64;
     if (nvec <= 1) LN_BWD(1); else if (nvec == 2) LN_BWD(2); else if (nvec == 3) LN_BWD(3); else if (nvec == 4) LN_BWD(4); else LN_BWD(LN_MAXV);
     STAR_LAUNCH_CHECK("star_layernorm_bwd");
-    hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3(cdiv(2 * D, 64)), dim3(1024), 0, (hipStream_t)stream, ws, dgamma, dbeta, nb, D);
+    hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3(cdiv(2 * D, 16)), dim3(1024), 0, (hipStream_t)stream, ws, dgamma, dbeta, nb, D);
     STAR_LAUNCH_CHECK("star_layernorm_bwd(reduce)");
     return 0;
 }

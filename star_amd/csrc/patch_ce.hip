@@ -13,7 +13,7 @@ __global__ __launch_bounds__(PC_THREADS) void patchify_kernel(const float* __res
                                                               int64_t s1h, int64_t s1w, const float* __restrict__ imgn,
                                                               int64_t snn, int64_t snt, int64_t snc, int64_t snh,
                                                               int64_t snw, T* __restrict__ out, int BA, int Tn, int C,
-                                                              int H, int W, int p, int korder) {
+                                                              int H, int W, int p, int korder, int vec) {
     const int gw = W / p, gh = H / p, L = gw * gh, K = C * p * p, kq = K >> 2;
     const int64_t item = (int64_t)blockIdx.x * PC_THREADS + threadIdx.x;
     if (item >= (int64_t)BA * Tn * L * kq) return;
@@ -31,6 +31,12 @@ __global__ __launch_bounds__(PC_THREADS) void patchify_kernel(const float* __res
         base = imgn + (int64_t)ba * snn + (int64_t)(t - 1) * snt; sc = snc; sh = snh; sw = snw;
     }
     float v[4];
+    if (vec) {   // channel-first image with unit pixel stride: the four values are one aligned 16-byte run of an image row
+        const int c = k0 / (p * p), r = k0 - c * p * p, py = r / p, px = r - py * p;
+        ld4(base + (int64_t)c * sc + (int64_t)(ty * p + py) * sh + (tx * p + px), v);
+        st4(out + row * K + k0, v);
+        return;
+    }
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
         const int k = k0 + e;
@@ -60,12 +66,17 @@ extern "C" int star_patchify(const float* img1, const int64_t* s1, const float* 
     const int adt = dt & 0xff;
     int64_t z5[5] = {0, 0, 0, 0, 0};
     if (!sn) sn = z5;
+    // 16-byte image reads need unit pixel stride, the (c,py,px) order, and every other stride / base a multiple of 4 floats
+    auto al4 = [](int64_t v) { return (v & 3) == 0; };
+    int vec = korder == 0 && (p & 3) == 0 && s1[3] == 1 && al4(s1[0]) && al4(s1[1]) && al4(s1[2]) && (reinterpret_cast<uintptr_t>(img1) & 15) == 0;
+    if (vec && T > 1)
+        vec = sn[4] == 1 && al4(sn[0]) && al4(sn[1]) && al4(sn[2]) && al4(sn[3]) && (reinterpret_cast<uintptr_t>(imgn) & 15) == 0;
     if (adt == STAR_BF16)
         hipLaunchKernelGGL(patchify_kernel<bf16_t>, dim3(cdiv(items, PC_THREADS)), dim3(PC_THREADS), 0, (hipStream_t)stream,
-                           img1, s1[0], s1[1], s1[2], s1[3], imgn, sn[0], sn[1], sn[2], sn[3], sn[4], (bf16_t*)out, BA, T, C, H, W, p, korder);
+                           img1, s1[0], s1[1], s1[2], s1[3], imgn, sn[0], sn[1], sn[2], sn[3], sn[4], (bf16_t*)out, BA, T, C, H, W, p, korder, vec);
     else
         hipLaunchKernelGGL(patchify_kernel<float>, dim3(cdiv(items, PC_THREADS)), dim3(PC_THREADS), 0, (hipStream_t)stream,
-                           img1, s1[0], s1[1], s1[2], s1[3], imgn, sn[0], sn[1], sn[2], sn[3], sn[4], (float*)out, BA, T, C, H, W, p, korder);
+                           img1, s1[0], s1[1], s1[2], s1[3], imgn, sn[0], sn[1], sn[2], sn[3], sn[4], (float*)out, BA, T, C, H, W, p, korder, vec);
     STAR_LAUNCH_CHECK("star_patchify");
     return 0;
 }
