@@ -30,6 +30,7 @@ class _StarFunction(torch.autograd.Function):
         P.update(model._frozen_tables())
         out, saved = engine.forward(model._cfg(), P, model._weights, model._dt(), train=True, **inputs)
         ctx.model, ctx.names, ctx.saved, ctx.P = model, names, saved, P
+        ctx.set_materialize_grads(False)      # no zero-filled gradients for result / latent / ind (400 MB of fills per step)
         extras = tuple(out[k] for k in _EXTRAS if k in out)
         ctx.mark_non_differentiable(out["result"], out["latent"], out["ind"], *extras)
         return (out["loss"].reshape(()), out["result"], out["latent"], out["ind"]) + extras
@@ -37,6 +38,8 @@ class _StarFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gloss, *_unused):
         model = ctx.model
+        if gloss is None:      # the loss took no gradient (materialisation is off): nothing to propagate
+            return (None, None, None) + (None,) * len(ctx.names)
         grads = engine.backward(model._cfg(), ctx.P, model._weights, model._dt(), ctx.saved, G=model._grad_views,
                                 on_ready=model._on_grads_ready)
         ctx.saved = None
