@@ -266,7 +266,7 @@ def _block_bwd(g, g_lp, s, P, W, dt, grads, G=None, side=None):
 
 # -------------------------------------------------------------------------------------------------------
 def forward(cfg, P, W, dt, imgs1, imgs_next, trans_matrices, num_agent, batch, mask_ratio, infer, train, noise=None, taps=None,
-            vq_update=False):
+            vq_update=False, theta=None):
     """Runs the model.  Returns (out, ctx): out = dict(loss [1], result, latent, ind); ctx feeds backward()."""
     dev = imgs1.device
     ba, c, hh, ww = imgs1.shape
@@ -373,7 +373,8 @@ def forward(cfg, P, W, dt, imgs1, imgs_next, trans_matrices, num_agent, batch, m
     ce = ops.ce_argmax(logits, imgs1, p, dt, want_pred=taps is not None, want_dlogits=train)
     if taps is not None:
         taps["pred"], taps["mask"], taps["ids_restore"] = ce["pred"], mask, ids_restore
-    theta = ops.warp_thetas(trans_matrices).pin_memory().to(dev, non_blocking=True)   # pinned: the copy does not block the host
+    if theta is None:    # a captured graph brings the pose table in a static device buffer instead (star_amd/graph.py)
+        theta = ops.warp_thetas(trans_matrices).pin_memory().to(dev, non_blocking=True)   # pinned: the copy does not block the host
     na = num_agent if num_agent.is_cuda else num_agent.to(dev)
     if na.dtype not in (torch.int32, torch.int64):
         na = na.long()

@@ -83,6 +83,7 @@ class AmortizedIndivMMAEViT(MultiAgentMaskedAutoencoderViT):
         self._on_grads_ready = None      # callback(stage) from the backward chain (bucketed all-reduce)
         self._noise_override = None      # tests: feed the mask noise instead of drawing it
         self._taps = None                # tests: dict that receives intermediate tensors
+        self._theta_override = None      # star_amd.graph: static device buffer with the warp table (replaces trans_matrices)
 
     # ---- engine plumbing --------------------------------------------------------------------------------
     def set_compute_dtype(self, name):
@@ -112,7 +113,7 @@ class AmortizedIndivMMAEViT(MultiAgentMaskedAutoencoderViT):
         self.num_agent = imgs1.shape[0] // batch_size
         return dict(imgs1=imgs1.float(), imgs_next=imgs_next.float() if imgs_next.dim() > 2 else imgs_next,
                     trans_matrices=trans_matrices, num_agent=num_agent_tensor, batch=batch_size, mask_ratio=mask_ratio,
-                    infer=infer, noise=self._noise_override, taps=self._taps, vq_update=self.training)
+                    infer=infer, noise=self._noise_override, taps=self._taps, vq_update=self.training, theta=self._theta_override)
 
     def _named_trainable(self):
         names, params = [], []

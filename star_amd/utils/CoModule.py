@@ -12,8 +12,11 @@ from .move_optim import optimizer_to
 
 
 class CoModule(object):
-    def __init__(self, model, optimizer, com, parallel=None):
-        """`parallel`: optional star_amd.parallel.SceneParallel (multi-GPU gradient averaging)."""
+    def __init__(self, model, optimizer, com, parallel=None, graph_inference=False):
+        """`parallel`: optional star_amd.parallel.SceneParallel (multi-GPU gradient averaging).
+        `graph_inference`: infer_mae_completion / infer_vqstar_completion replay a captured HIP graph (star_amd.graph): same
+        results (no speed-up measured: see that module); the returned tensors are overwritten by the next call."""
+        self._graphed = {} if graph_inference else None
         self.mae_loss_scaler = NativeScaler()
         self.model = model
         self.optimizer = optimizer
@@ -91,13 +94,22 @@ class CoModule(object):
         """star/utils/CoModule.py:231-253 -> (loss, result, ind_pred, perplexity, encodings)."""
         bev_seq, bev_seq_next, bev_teacher, trans_matrices, num_agent_tensor = self._unpack(data)
         with torch.no_grad():
-            loss, result, ind_pred, perplexity, encodings = self.model.inference(bev_seq, bev_seq_next, bev_teacher, trans_matrices,
-                                                                                 num_agent_tensor, batch_size, mask_ratio=mask_ratio)
+            loss, result, ind_pred, perplexity, encodings = self._inference(bev_seq, bev_seq_next, bev_teacher, trans_matrices,
+                                                                            num_agent_tensor, batch_size, mask_ratio)
         return loss.item(), result, ind_pred.detach(), perplexity.detach(), encodings.detach()
 
     def infer_mae_completion(self, data, batch_size, mask_ratio, loss_fn='mse'):
         bev_seq, bev_seq_next, bev_teacher, trans_matrices, num_agent_tensor = self._unpack(data)
         with torch.no_grad():
-            loss, result, latent, ind_pred = self.model.inference(bev_seq, bev_seq_next, bev_teacher, trans_matrices,
-                                                                  num_agent_tensor, batch_size, mask_ratio=mask_ratio)
+            loss, result, latent, ind_pred = self._inference(bev_seq, bev_seq_next, bev_teacher, trans_matrices, num_agent_tensor,
+                                                             batch_size, mask_ratio)
         return loss.item(), result, ind_pred.detach(), latent.detach()
+
+    def _inference(self, bev_seq, bev_seq_next, bev_teacher, trans_matrices, num_agent_tensor, batch_size, mask_ratio):
+        if self._graphed is None:
+            return self.model.inference(bev_seq, bev_seq_next, bev_teacher, trans_matrices, num_agent_tensor, batch_size, mask_ratio=mask_ratio)
+        run = self._graphed.get((batch_size, mask_ratio))
+        if run is None:
+            from star_amd.graph import GraphedInference
+            run = self._graphed[(batch_size, mask_ratio)] = GraphedInference(self.model, batch_size, mask_ratio)
+        return run(bev_seq, bev_seq_next, bev_teacher, trans_matrices, num_agent_tensor)
