@@ -14,6 +14,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from star.models import VQSTAR, multiagent_mae  # noqa: E402
 from star.utils.CoModule import CoModule  # noqa: E402
 from star.utils.metrics import Metrics  # noqa: E402
+from star_amd.datasets import SparseSceneDataset, discover  # noqa: E402
 from star_amd.synthetic import make_batch  # noqa: E402
 
 
@@ -34,14 +35,21 @@ def main(args):
     model.eval()
     optimizer = torch.optim.AdamW(model.parameters(), lr=args.lr)
     co_module = CoModule(model, optimizer, args.com)
+    if args.data != "synthetic":     # a pre-processed V2X-Sim split in the reference's on-disk format, in file order
+        dataset = SparseSceneDataset(*discover(args.data, args.num_agent, args.no_cross_road), time_stamp=args.time_stamp,
+                                     no_cross_road=args.no_cross_road)
+        print("Validation dataset size:", len(dataset))
+        args.iters = dataset.steps_per_epoch(args.batch)
+        batches = dataset.loader(args.batch, shuffle=False, num_workers=args.nworker, device=device)
+    else:
+        batches = ((make_batch(args.batch, num_agent, args.time_stamp, seed=10_000 + it, device=device), args.batch) for it in range(args.iters))
     evaluator = Metrics(2, args.iters)
     losses = 0.0
-    for it in range(args.iters):
-        data = make_batch(args.batch, num_agent, args.time_stamp, seed=10_000 + it, device=device)
+    for data, bsz in batches:
         if args.com == "vqstar":
-            loss, reconstruction, ind_pred, perplexity, encodings = co_module.infer_vqstar_completion(data, args.batch, args.mask_ratio)
+            loss, reconstruction, ind_pred, perplexity, encodings = co_module.infer_vqstar_completion(data, bsz, args.mask_ratio)
         else:
-            loss, reconstruction, ind_pred, latent = co_module.infer_mae_completion(data, args.batch, args.mask_ratio)
+            loss, reconstruction, ind_pred, latent = co_module.infer_mae_completion(data, bsz, args.mask_ratio)
         teacher = data["bev_seq_teacher"].squeeze(1).permute(0, 3, 1, 2)
         evaluator.add_batch(reconstruction, teacher.contiguous())
         evaluator.update_IoU()
@@ -72,4 +80,5 @@ if __name__ == "__main__":
     p.add_argument("--vq_embedding_dim", default=64, type=int)
     p.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     p.add_argument("--iters", default=10, type=int, help="synthetic batches to evaluate")
+    p.add_argument("--nworker", default=2, type=int)
     main(p.parse_args())

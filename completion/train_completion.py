@@ -3,7 +3,8 @@
 completion/train_completion.py with the same flags, learning-rate schedule, log lines and checkpoint layout
 (`completion_epoch_<n>.pth` holding epoch / model_state_dict / optimizer_state_dict / scheduler_state_dict /
 mae_scaler_state_dict / loss).  The V2X-Sim loader of the reference needs the absent `coperception` package and
-dataset, so batches come from star_amd.synthetic with the same per-batch dictionary layout.
+dataset class; `-d <root>` reads the same pre-processed sample files through star_amd.datasets (sparse indices, densified on
+the GPU), `-d synthetic` (default) draws batches from star_amd.synthetic with the same per-batch dictionary layout.
 
 Single GPU:   python completion/train_completion.py --com ind_mae --mae_model amortized_ind_patch8_light \\
                   --mask complement --time_stamp 1 --batch 8 --nepoch 2 --log --logpath logs
@@ -23,6 +24,7 @@ from star.utils import lr_sched  # noqa: E402
 from star.utils.CoModule import CoModule  # noqa: E402
 from star_amd.optim import FlatAdamW, add_weight_decay  # noqa: E402
 from star_amd.parallel import SceneParallel  # noqa: E402
+from star_amd.datasets import SparseSceneDataset, discover  # noqa: E402
 from star_amd.synthetic import make_batch  # noqa: E402
 
 
@@ -104,7 +106,20 @@ def main(args):
         saver.write(args.__repr__() + "\n\n")
         saver.flush()
 
-    iters = args.iters_per_epoch
+    dataset = None
+    if args.data != "synthetic":     # a pre-processed V2X-Sim split: <data>/agent<i>/<scene>_<frame>/<sample>.npy (reference layout)
+        dataset = SparseSceneDataset(*discover(args.data, args.num_agent, args.no_cross_road), time_stamp=args.time_stamp,
+                                     no_cross_road=args.no_cross_road)
+        print("Training dataset size:", len(dataset))
+    iters = args.iters_per_epoch if dataset is None else dataset.steps_per_epoch(args.batch, world)
+
+    def batches(epoch):
+        if dataset is None:
+            for it in range(iters):
+                yield make_batch(args.batch, num_agent, args.time_stamp, seed=(epoch * iters + it) * world + rank + 1, device=device), args.batch
+        else:
+            yield from dataset.loader(args.batch, shuffle=True, num_workers=args.nworker, device=device, seed=epoch, rank=rank, world=world)
+
     for epoch in range(start_epoch, args.nepoch + 1):
         lr = co_module.optimizer.param_groups[0]["lr"]
         if rank == 0:
@@ -113,13 +128,12 @@ def main(args):
             saver.write("epoch: {}, lr: {}\t".format(epoch, lr))
         running = AverageMeter("Total loss", ":.6f")
         co_module.model.train()
-        for it in range(iters):
-            data = make_batch(args.batch, num_agent, args.time_stamp, seed=(epoch * iters + it) * world + rank + 1, device=device)
+        for it, (data, bsz) in enumerate(batches(epoch)):
             lr_sched.adjust_learning_rate(co_module.optimizer, it / iters + epoch, args)
             if vq:
-                loss, reconstruction, _, perplexity = co_module.step_vqstar_completion(data, args.batch, args.mask_ratio, trainable=True)
+                loss, reconstruction, _, perplexity = co_module.step_vqstar_completion(data, bsz, args.mask_ratio, trainable=True)
             else:
-                loss, reconstruction, _ = co_module.step_mae_completion(data, args.batch, args.mask_ratio, trainable=True)
+                loss, reconstruction, _ = co_module.step_mae_completion(data, bsz, args.mask_ratio, trainable=True)
             running.update(loss)
             if it % args.logstep == 0 and rank == 0:
                 print("**Epoch {} -- iterstep {}** : imme loss {:.6f}, running loss {:.6f}, current lr {:.6f}".format(
@@ -142,7 +156,8 @@ def main(args):
 
 if __name__ == "__main__":
     p = argparse.ArgumentParser()
-    p.add_argument("-d", "--data", default="synthetic", type=str, help="only 'synthetic' batches are available here")
+    p.add_argument("-d", "--data", default="synthetic", type=str,
+                   help="'synthetic', or the root of a pre-processed V2X-Sim split (agent<i>/<scene>_<frame>/ sample files, reference format)")
     p.add_argument("--batch", default=4, type=int, help="Batch size (scenes per GPU)")
     p.add_argument("--nepoch", default=100, type=int)
     p.add_argument("--nworker", default=2, type=int)

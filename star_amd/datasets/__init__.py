@@ -1,1 +1,1 @@
-from .voxel import SparseSceneDataset, collate_sparse, densify, past_frame_indices, read_sample, write_sample  # noqa: F401
+from .voxel import SparseSceneDataset, collate_sparse, densify, discover, past_frame_indices, read_sample, write_sample  # noqa: F401

@@ -112,6 +112,35 @@ def collate_sparse(scenes, time_stamp, device="cuda", dims=DIMS, no_cross_road=F
     return data
 
 
+def discover(data_root, num_agent=6, no_cross_road=False):
+    """File tables of a pre-processed V2X-Sim split laid out the way the reference's scripts pass it to the dataset class
+    (completion/train_completion.py:66-69: `dataset_roots = [f"{data}/agent{i}" ...]`, agents 1.. when --no_cross_road):
+    every agent directory holds one directory `<scene>_<frame>` per frame with the sample file inside.  The ordering --
+    by (scene, frame) as integers -- and the scene id = the directory prefix are those of the coperception base class
+    (V2XSimDet.__init__), a third-party package that is absent here: restated from its published source, parity unpinned.
+    -> (files[a][i], seq_scenes[a][i]) for SparseSceneDataset."""
+    import os
+    files, seq_scenes = [], []
+    for a in (range(1, num_agent) if no_cross_road else range(num_agent)):
+        root = os.path.join(data_root, "agent%d" % a)
+        dirs = [d for d in os.listdir(root) if os.path.isdir(os.path.join(root, d))]
+        dirs.sort(key=lambda x: (int(x.split("_")[0]), int(x.split("_")[1])))
+        seq_scenes.append([int(d.split("_")[0]) for d in dirs])
+        row = []
+        for d in dirs:
+            inside = sorted(f for f in os.listdir(os.path.join(root, d)) if os.path.isfile(os.path.join(root, d, f)))
+            assert inside, "no sample file in %s" % os.path.join(root, d)
+            row.append(os.path.join(root, d, inside[0]))
+        files.append(row)
+    n = len(files[0])
+    assert all(len(r) == n for r in files), "agents hold different numbers of frames: %r" % [len(r) for r in files]
+    return files, seq_scenes
+
+
+def _identity(scenes):     # module-level: DataLoader workers pickle the collate function
+    return scenes
+
+
 class SparseSceneDataset:
     """Per-agent frame files in the reference's format -> sparse scene samples for `collate_sparse`.
     files[a][i] is agent a's i-th frame file, seq_scenes[a][i] its scene id (the two tables the coperception
@@ -123,6 +152,33 @@ class SparseSceneDataset:
 
     def __len__(self):
         return len(self.files[0])
+
+    def loader(self, batch_size, shuffle=True, num_workers=0, device="cuda", seed=None, rank=0, world=1):
+        """Batches for CoModule: a torch DataLoader over the sparse samples (file reads in worker processes, nothing dense
+        crosses PCIe), densified by one star_voxel_scatter launch per batch in the consuming process.  With world > 1 every
+        rank walks its own share of one common permutation (whole scenes per rank), cut to equal length so that the ranks
+        take the same number of steps.  Yields (data dict, scenes in this batch)."""
+        for scenes in self.scene_batches(batch_size, shuffle, num_workers, seed, rank, world):
+            yield collate_sparse(scenes, self.time_stamp, device=device, no_cross_road=self.no_cross_road), len(scenes)
+
+    def scene_batches(self, batch_size, shuffle=True, num_workers=0, seed=None, rank=0, world=1):
+        """The host half of `loader`: lists of sparse scenes, in this rank's order."""
+        from torch.utils.data import DataLoader, Subset
+        n = len(self)
+        if shuffle:
+            gen = torch.Generator()
+            gen.manual_seed(0 if seed is None else int(seed))
+            order = torch.randperm(n, generator=gen).tolist()
+        else:
+            order = list(range(n))
+        if world > 1:
+            order = order[:n - n % world][rank::world]
+        yield from DataLoader(Subset(self, order), batch_size=batch_size, shuffle=False, num_workers=num_workers, collate_fn=_identity)
+
+    def steps_per_epoch(self, batch_size, world=1):
+        n = len(self)
+        per_rank = (n - n % world) // world if world > 1 else n
+        return (per_rank + batch_size - 1) // batch_size
 
     def __getitem__(self, idx):
         scene = []

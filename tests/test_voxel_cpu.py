@@ -68,3 +68,57 @@ def test_sample_file_round_trip(tmp_path):
     assert np.array_equal(d["voxel_indices_0"], idx) and d["num_sensor"] == 4 and d["target_agent_id"] == 2
     assert np.array_equal(d["trans_matrices_no_cross_road"], tm * 2)
     assert V.read_sample(str(tmp_path / "empty.npy")) is None
+
+
+def _write_split(root, n_agents, frames, rng, empty=()):
+    """frames: list of (scene, frame) -> <root>/agent<a>/<scene>_<frame>/0.npy in the reference's sample format."""
+    import os
+    truth = {}
+    for a in range(n_agents):
+        for (sc, fr) in frames:
+            d = os.path.join(root, "agent%d" % a, "%d_%d" % (sc, fr))
+            os.makedirs(d)
+            if (a, sc, fr) in empty:
+                V.write_sample(os.path.join(d, "0.npy"), None, None, None, 0)
+                continue
+            vox = np.stack([rng.randint(0, 256, 200), rng.randint(0, 256, 200), rng.randint(0, 13, 200)], 1)
+            tea = np.stack([rng.randint(0, 256, 300), rng.randint(0, 256, 300), rng.randint(0, 13, 300)], 1)
+            trans = rng.randn(n_agents, 4, 4)
+            V.write_sample(os.path.join(d, "0.npy"), vox, tea, trans, n_agents, a)
+            truth[(a, sc, fr)] = (vox, tea, trans)
+    return truth
+
+
+def test_discover_orders_frames_by_scene_then_frame_and_dataset_reads_them(tmp_path):
+    rng = np.random.RandomState(3)
+    frames = [(10, 2), (9, 15), (2, 10), (2, 9), (10, 0)]           # string order would differ from integer order
+    truth = _write_split(str(tmp_path), 3, frames, rng, empty={(1, 9, 15)})
+    files, seq_scenes = V.discover(str(tmp_path), num_agent=3)
+    want = sorted(frames)
+    assert seq_scenes == [[s for s, _ in want]] * 3
+    for a in range(3):
+        assert [f.split("/")[-2] for f in files[a]] == ["%d_%d" % sf for sf in want]
+    ds = V.SparseSceneDataset(files, seq_scenes, time_stamp=2)
+    assert len(ds) == 5 and ds.steps_per_epoch(2) == 3 and ds.steps_per_epoch(2, world=2) == 1
+    for i, (sc, fr) in enumerate(want):
+        scene = ds[i]
+        for a in range(3):
+            if (a, sc, fr) not in truth:
+                assert scene[a] is None
+                continue
+            vox, tea, trans = truth[(a, sc, fr)]
+            assert np.array_equal(scene[a]["voxels"][0], vox) and np.array_equal(scene[a]["teacher"], tea)
+            assert np.array_equal(scene[a]["trans_matrices"], trans) and scene[a]["num_sensor"] == 3
+            k = V.past_frame_indices(seq_scenes[a], i, 2)[0]
+            past = truth.get((a,) + want[k])
+            assert np.array_equal(scene[a]["voxels"][1], vox if past is None else past[0])     # empty past slot -> the current frame
+    # --no_cross_road: agents 1.. only
+    files1, _ = V.discover(str(tmp_path), num_agent=3, no_cross_road=True)
+    assert len(files1) == 2 and "agent1" in files1[0][0]
+    # rank shares: disjoint, equal length, together one permutation prefix
+    a0 = [id_ for b in ds.scene_batches(1, shuffle=True, seed=7, rank=0, world=2) for id_ in map(id, b)]
+    seen = []
+    for r in range(2):
+        for b in ds.scene_batches(2, shuffle=True, seed=7, rank=r, world=2):
+            seen.append((r, len(b)))
+    assert [n for _, n in seen] == [2, 2] and len(a0) == 2
