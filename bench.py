@@ -68,6 +68,17 @@ def _pmc_traffic(family):
     return round(tot / n) if n else None
 
 
+def _pmc_mfma_util(family):
+    """Fraction of SIMD cycles with the MFMA pipe busy for the family, from the committed PMC summary (tools/pmc_mfma.sh over
+    this same bench command); None if absent."""
+    path = os.path.join(ROOT, "profiles", "r01_h_pmc_mfma.json")
+    if not os.path.exists(path):
+        return None
+    with open(path) as f:
+        v = json.load(f)["families"].get(family)
+    return round(v["mfma_util_busy_cycles"], 4) if v and v.get("mfma_util_busy_cycles") is not None else None
+
+
 def cpu_baseline(args, cores):
     """The CPU oracle's training step (fp32 PyTorch-CPU restatement of the reference path + AdamW) on ONE
     synthetic scene of the same law; 1 warm-up + 2 timed steps (about 10-20 s)."""
@@ -221,6 +232,9 @@ def main():
         traffic = _pmc_traffic(dominant)
         if traffic is not None:
             roof["traffic"] = traffic
+        util = _pmc_mfma_util(dominant)
+        if util is not None:
+            roof["mfma_util_pmc"] = util
         if args.profile_all:
             tot = sum(v["ms"] for v in probe.values())
             for k, v in sorted(probe.items(), key=lambda kv: -kv[1]["ms"]):
