@@ -63,6 +63,10 @@ class SceneParallel:
 
     def finish(self):
         """Make the compute stream wait for every outstanding bucket (call between backward and step)."""
+        if self.deferred and not self.native_avg and self.opt.flat_g.is_cuda:
+            # gloo stages device tensors through the host from its own threads; with the backward chain still running on a GPU
+            # that the ranks share, its second step was seen to stall: the rehearsal path drains the device first
+            torch.cuda.synchronize()
         for rng in self.deferred:
             self._launch(rng)
         self.deferred = []
