@@ -250,6 +250,9 @@ def _ln_bwd(grads, G, name, dy, x, P, mean, rstd, g_in=None):
 # best partner for it) instead of beside the memory-bound dgrad GEMMs and LayerNorm in between; the other three start as soon as
 # their operands exist.  A/B inside one GPU call: this order 12.75 ms/step, all three early ones deferred 12.85, none 12.92.
 WG_DEFER = os.environ.get("STAR_AMD_WG_DEFER", "1") == "1"
+# the weight gradients outside the blocks (prediction heads, decoder_embed, decompressor, compressor) run on the side stream too:
+# A/B inside one GPU call 13.51 -> 13.35 ms/step
+SIDE_EXTRA = os.environ.get("STAR_AMD_SIDE_EXTRA", "1") == "1"
 
 
 def _block_bwd(g, g_lp, s, P, W, dt, grads, G=None, side=None):
@@ -417,21 +420,30 @@ def backward(cfg, P, W, dt, ctx, G=None, on_ready=None):
     save = ctx["save"]
     dlog = ctx["dlogits"]
     side = _SideStream(dlog.device) if SIDE_STREAM and G is not None else None
-    # prediction heads
-    dw, db = ops.gemm_wgrad(dlog, ctx["yd"])
-    idx = head_permutation(cfg, dw.device)
-    V = cfg.V
-    for name, lo in (("decoder_pred_free", 0), ("decoder_pred_occ", V)):
-        gw = torch.empty(V, Dd, dtype=torch.float32, device=dw.device)
-        gb = torch.empty(V, dtype=torch.float32, device=dw.device)
-        gw.index_copy_(0, idx, dw[lo:lo + V])
-        gb.index_copy_(0, idx, db[lo:lo + V])
-        _put(grads, G, name + ".weight", gw)
-        _put(grads, G, name + ".bias", gb)
+    # prediction heads: weight gradient (and its row permutation back to the reference order) beside the dgrad chain
+    side_x = side if SIDE_EXTRA else None
+
+    def heads_wgrad():
+        dw, db = ops.gemm_wgrad(dlog, ctx["yd"])
+        idx = head_permutation(cfg, dw.device)
+        V = cfg.V
+        for name, lo in (("decoder_pred_free", 0), ("decoder_pred_occ", V)):
+            gw = torch.empty(V, Dd, dtype=torch.float32, device=dw.device)
+            gb = torch.empty(V, dtype=torch.float32, device=dw.device)
+            gw.index_copy_(0, idx, dw[lo:lo + V])
+            gb.index_copy_(0, idx, db[lo:lo + V])
+            _put(grads, G, name + ".weight", gw)
+            _put(grads, G, name + ".bias", gb)
+    if side_x is None:
+        heads_wgrad()
+    else:
+        side_x.run(heads_wgrad, dlog, ctx["yd"])
     dyd, _, _ = ops.gemm(dlog, _heads(P, W, cfg, dt, True))
     g, g_lp = _ln_bwd(grads, G, "decoder_norm", dyd, ctx["xd"], P, ctx["mean_d"], ctx["rstd_d"])
     stage = 0
     if on_ready is not None:
+        if side_x is not None:
+            side_x.join()
         on_ready(stage)
     for s in reversed(save[cfg.depth:]):
         g, g_lp = _block_bwd(g, g_lp, s, P, W, dt, grads, G, side)
@@ -453,9 +465,9 @@ def backward(cfg, P, W, dt, ctx, G=None, on_ready=None):
         if ctx["random_mode"]:
             gt[0] += gtok[0]                                                        # mask tokens carry temp_embed[0]
         _put(grads, G, "decoder_temp_embed", gt.reshape(1, T, 1, Dd))
-    _wg(grads, G, "decoder_embed", dye, ctx["z"])
+    _wg(grads, G, "decoder_embed", dye, ctx["z"], side=side_x)
     dz, _, _ = ops.gemm(dye, _lin(P, W, "decoder_embed", dt, True))
-    _wg(grads, G, "decompressor", dz, ctx["dec_in_lp"])
+    _wg(grads, G, "decompressor", dz, ctx["dec_in_lp"], side=side_x)
     if cfg.vq:
         # straight-through estimator: the decoder's gradient passes to the latent, plus the commitment term; the codebook
         # only sees the q_latent term (mae_base.py:162-166); then the compressor's ReLU
@@ -470,12 +482,14 @@ def backward(cfg, P, W, dt, ctx, G=None, on_ready=None):
     else:
         dlat, _, _ = ops.gemm(dz, _lin(P, W, "decompressor", dt, True), act=ACT_DRELU, aux=ctx["latent_lp"])
     comp_rows = None if cfg.encode_partial else ctx["src_row"]
-    _wg(grads, G, "compressor.0", dlat, ctx["y"], x_rows=comp_rows)
+    _wg(grads, G, "compressor.0", dlat, ctx["y"], x_rows=comp_rows, side=side_x)
     rows_enc = n_frames * ctx["l_enc"]
     dy, _, _ = ops.gemm(dlat, _lin(P, W, "compressor.0", dt, True), c_rows=comp_rows, out_rows=rows_enc)
     g, g_lp = _ln_bwd(grads, G, "norm", dy, ctx["x_enc"], P, ctx["mean_e"], ctx["rstd_e"])
     stage += 1
     if on_ready is not None:
+        if side_x is not None:
+            side_x.join()
         on_ready(stage)
     for s in reversed(save[:cfg.depth]):
         g, g_lp = _block_bwd(g, g_lp, s, P, W, dt, grads, G, side)
