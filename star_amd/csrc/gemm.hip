@@ -288,7 +288,7 @@ __device__ __forceinline__ int ntf_swz(int row) { return (0x78 >> (((row >> 2) &
 #define EPI_GENERIC 0   // everything decided at run time
 #define EPI_LINEAR 1    // bias only (any row gather / scatter); no activation, residual, aux, pre
 #define EPI_RES 2       // bias + one float32 residual table; no activation
-#define EPI_GELU_GRAD 3 // bias + GELU, `pre` receives gelu' (STAR_GEMM_PRE_IS_GRAD)
+#define EPI_GELU_GRAD 3 // bias + GELU; `pre`, when given, receives gelu' (STAR_GEMM_PRE_IS_GRAD)
 #define EPI_MULAUX 4    // times aux; no bias, no residual
 // Tile geometry: WM x WN waves, each wave RB 16-row blocks (rows) x 64 columns.
 //   <2,2,4>: 128 x 128, 4 waves (3 blocks per CU)   -- narrow outputs (N <= 256) and small problems
@@ -377,7 +377,7 @@ void gemm_nt_fast_kernel(const StarGemm g) {
     constexpr bool GEN = EPI == EPI_GENERIC;
     const bool by_arow = (EPI == EPI_GENERIC || EPI == EPI_RES) && (g.flags & STAR_GEMM_RES_BY_AROW) != 0;
     const bool pre_grad = GEN ? (g.flags & STAR_GEMM_PRE_IS_GRAD) != 0 : true;
-    const bool has_pre = GEN ? pre != nullptr : EPI == EPI_GELU_GRAD;
+    const bool has_pre = GEN ? pre != nullptr : (EPI == EPI_GELU_GRAD && pre != nullptr);   // inference: GELU without its derivative
     const bool has_bias = EPI == EPI_MULAUX ? false : g.bias != nullptr;
     const bool has_res = GEN ? g.res != nullptr : EPI == EPI_RES;
     const bool has_res2 = GEN && g.res2 != nullptr;
@@ -864,7 +864,7 @@ static int launch_nt_fast(const StarGemm* g, hipStream_t s) {
     if (plain && !g->res && launch_nt_wreg(g, s)) return 0;
     if (plain && !g->res) launch_nt_fast_epi<NST, EPI_LINEAR>(g, s);
     else if (plain) launch_nt_fast_epi<NST, EPI_RES>(g, s);
-    else if (g->act == STAR_ACT_GELU && g->pre && (g->flags & STAR_GEMM_PRE_IS_GRAD) && !g->res && !g->res2) launch_nt_fast_epi<NST, EPI_GELU_GRAD>(g, s);
+    else if (g->act == STAR_ACT_GELU && (!g->pre || (g->flags & STAR_GEMM_PRE_IS_GRAD)) && !g->aux && !g->res && !g->res2) launch_nt_fast_epi<NST, EPI_GELU_GRAD>(g, s);
     else if (g->act == STAR_ACT_MULAUX && !g->bias && !g->res && !g->res2 && !g->pre) launch_nt_fast_epi<NST, EPI_MULAUX>(g, s);
     else launch_nt_fast_epi<NST, EPI_GENERIC>(g, s);
     return 0;
