@@ -31,9 +31,15 @@ __global__ __launch_bounds__(PC_THREADS) void patchify_kernel(const float* __res
         base = imgn + (int64_t)ba * snn + (int64_t)(t - 1) * snt; sc = snc; sh = snh; sw = snw;
     }
     float v[4];
-    if (vec) {   // channel-first image with unit pixel stride: the four values are one aligned 16-byte run of an image row
+    if (vec == 1) {   // channel-first image with unit pixel stride: the four values are one aligned 16-byte run of an image row
         const int c = k0 / (p * p), r = k0 - c * p * p, py = r / p, px = r - py * p;
         ld4(base + (int64_t)c * sc + (int64_t)(ty * p + py) * sh + (tx * p + px), v);
+        st4(out + row * K + k0, v);
+        return;
+    }
+    if (vec == 2) {   // channels-last image (unit channel stride, pixel stride C) in the (py,px,c) order: a patch row is p*C consecutive floats
+        const int py = k0 / (p * C), r = k0 - py * p * C;
+        ld4(base + (int64_t)(ty * p + py) * sh + (int64_t)tx * p * C + r, v);
         st4(out + row * K + k0, v);
         return;
     }
@@ -71,6 +77,10 @@ extern "C" int star_patchify(const float* img1, const int64_t* s1, const float* 
     int vec = korder == 0 && (p & 3) == 0 && s1[3] == 1 && al4(s1[0]) && al4(s1[1]) && al4(s1[2]) && (reinterpret_cast<uintptr_t>(img1) & 15) == 0;
     if (vec && T > 1)
         vec = sn[4] == 1 && al4(sn[0]) && al4(sn[1]) && al4(sn[2]) && al4(sn[3]) && (reinterpret_cast<uintptr_t>(imgn) & 15) == 0;
+    if (!vec && korder == 1 && (p * C) % 4 == 0 && s1[1] == 1 && s1[3] == C && al4(s1[0]) && al4(s1[2]) && (reinterpret_cast<uintptr_t>(img1) & 15) == 0) {
+        vec = 2;
+        if (T > 1 && !(sn[2] == 1 && sn[4] == C && al4(sn[0]) && al4(sn[1]) && al4(sn[3]) && (reinterpret_cast<uintptr_t>(imgn) & 15) == 0)) vec = 0;
+    }
     if (adt == STAR_BF16)
         hipLaunchKernelGGL(patchify_kernel<bf16_t>, dim3(cdiv(items, PC_THREADS)), dim3(PC_THREADS), 0, (hipStream_t)stream,
                            img1, s1[0], s1[1], s1[2], s1[3], imgn, sn[0], sn[1], sn[2], sn[3], sn[4], (bf16_t*)out, BA, T, C, H, W, p, korder, vec);
