@@ -121,8 +121,9 @@ __global__ __launch_bounds__(PC_THREADS) void ce_argmax_kernel(const float* __re
             const float d = o[e] - f[e];
             // log(exp(f) + exp(o)) - chosen  ==  softplus(+-d)
             const float z = tc ? -d : d;
-            lsum += fmaxf(z, 0.f) + log1pf(expf(-fabsf(z)));
-            const float p1 = 1.0f / (1.0f + expf(-d));  // softmax prob of "occupied"
+            const float en = expf(-fabsf(d));            // one exponential serves the loss and the probability (|z| == |d|)
+            lsum += fmaxf(z, 0.f) + log1pf(en);
+            const float p1 = (d >= 0.f ? 1.0f : en) / (1.0f + en);  // softmax prob of "occupied" = sigmoid(d)
             dO[e] = (p1 - (float)tc) * inv_count;
             df[e] = -dO[e];
             dec[e] = o[e] > f[e] ? 1 : 0;  // argmax(softmax): ties -> class 0
