@@ -71,7 +71,7 @@ def _pmc_traffic(family):
 def _pmc_mfma_util(family):
     """Fraction of SIMD cycles with the MFMA pipe busy for the family, from the committed PMC summary (tools/pmc_mfma.sh over
     this same bench command); None if absent."""
-    path = os.path.join(ROOT, "profiles", "r01_k_pmc_mfma.json")
+    path = os.path.join(ROOT, "profiles", "r01_l_pmc_mfma.json")
     if not os.path.exists(path):
         return None
     with open(path) as f:
