@@ -4,7 +4,10 @@ one device).  usage (under torch.distributed.run): rehearse_dp.py nopar|sync|asy
   nopar : two independent processes, no gradient exchange (does GPU sharing itself work?)
   sync  : blocking all_reduce of the whole flat gradient after backward
   async : SceneParallel with the buckets launched from the backward thread (the RCCL default)
-  defer : SceneParallel with the buckets launched in finish() (the gloo default)"""
+  defer : SceneParallel with the buckets launched in finish() (the gloo default)
+Known limit of the vehicle (not of the RCCL path, where every rank owns its GPU): with two processes sharing the GPU and gloo
+staging device tensors through the host, a run occasionally stalls on its second step with one rank inside a device
+synchronize (seen with and without the side stream, before and after unrelated changes); rerun.  The watchdog below ends it."""
 import faulthandler
 import os
 import sys
