@@ -152,20 +152,24 @@ def pack(t):
 _SD_DONE = set()
 
 
-def gen_model_case(mm, name, ctor, T, mask, flags, B, A, num_agent, S, mask_ratio, mode, seed, with_grads):
-    sd_name = "sd_%s_T%d" % (ctor.__name__, T)
-    torch.manual_seed(0)
-    model = ctor(img_size=S, time_stamp=T, mask_method=mask, **flags)
-    # make every parameter non-trivial so that unused/zero-init ones are exercised too
-    torch.manual_seed(7)
-    with torch.no_grad():
-        model.decoder_temp_embed.normal_(std=0.02)
-        for n_, p in model.named_parameters():
-            if n_.endswith(".bias") or "norm" in n_:
-                p.add_(torch.randn_like(p) * 0.05)
+def gen_model_case(mm, name, ctor, T, mask, flags, B, A, num_agent, S, mask_ratio, mode, seed, with_grads, model=None, sd_name=None,
+                   inputs=None):
+    """model / sd_name / inputs: a prepared (e.g. trained) reference model and its input maps instead of the seeded
+    random-init model and random-bit maps (gen_golden_trained.py)."""
+    if model is None:
+        sd_name = "sd_%s_T%d" % (ctor.__name__, T)
+        torch.manual_seed(0)
+        model = ctor(img_size=S, time_stamp=T, mask_method=mask, **flags)
+        # make every parameter non-trivial so that unused/zero-init ones are exercised too
+        torch.manual_seed(7)
+        with torch.no_grad():
+            model.decoder_temp_embed.normal_(std=0.02)
+            for n_, p in model.named_parameters():
+                if n_.endswith(".bias") or "norm" in n_:
+                    p.add_(torch.randn_like(p) * 0.05)
     model.train() if mode == "train" else model.eval()
     rng = np.random.RandomState(seed)
-    bev, nxt, teacher = make_inputs(seed, B, A, T, S)
+    bev, nxt, teacher = make_inputs(seed, B, A, T, S) if inputs is None else inputs
     trans = torch.from_numpy(make_trans(rng, B, A))
     na = torch.tensor(num_agent, dtype=torch.int64).reshape(B, 1).repeat(1, A)
 
