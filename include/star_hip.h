@@ -85,6 +85,16 @@ int star_layernorm_bwd(const void* dy, const float* x, const float* gamma, const
                        const float* rstd, const float* g_in, float* g_out, void* g_out_lp, float* dgamma,
                        float* dbeta, float* ws, int M, int D, int dt, void* stream);
 
+/* Allocation-free variant of star_layernorm_bwd.  It has NO counterpart in the reference: it exists for callers that
+ * cannot allocate device memory or bring a workspace (code under HIP graph capture, tight serving loops, harnesses
+ * that forbid hipMalloc).  Same kernels and results, bit for bit; the partial dgamma/dbeta rows live in a 6 MiB
+ * file-scope device array of the library (one copy per GPU, held until the process ends) instead of `ws`.
+ * Limit: D <= 1024 (a larger D is rejected with an error; use star_layernorm_bwd).  Every call on a GPU shares that
+ * GPU's array: calls that overlap on one GPU (two streams, two threads) race. */
+int star_layernorm_bwd_static(const void* dy, const float* x, const float* gamma, const float* mean,
+                              const float* rstd, const float* g_in, float* g_out, void* g_out_lp, float* dgamma,
+                              float* dbeta, int M, int D, int dt, void* stream);
+
 /* ---- K3: Linear layers -------------------------------------------------------------------------------
  * Replaces every nn.Linear on the path (timm Attention.qkv/proj, Mlp.fc1/fc2, compressor,
  * decompressor, decoder_embed, decoder_pred_occ/free; mae_base.py:279-317) and, with the patch

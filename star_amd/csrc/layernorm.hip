@@ -204,9 +204,9 @@ extern "C" int star_layernorm_fwd(const float* x, const float* gamma, const floa
 
 extern "C" int64_t star_layernorm_bwd_ws(int D) { return (int64_t)LN_BWD_BLOCKS * 2 * D; }
 
-extern "C" int star_layernorm_bwd(const void* dy, const float* x, const float* gamma, const float* mean,
-                                  const float* rstd, const float* g_in, float* g_out, void* g_out_lp, float* dgamma,
-                                  float* dbeta, float* ws, int M, int D, int dt, void* stream) {
+static int ln_bwd_launch(const void* dy, const float* x, const float* gamma, const float* mean, const float* rstd,
+                         const float* g_in, float* g_out, void* g_out_lp, float* dgamma, float* dbeta, float* ws, int M, int D,
+                         int dt, void* stream) {
     STAR_CHECK(dy && x && gamma && mean && rstd && ws, "star_layernorm_bwd: null pointer");
     STAR_CHECK(M > 0 && D >= 4 && D % 4 == 0 && D <= 64 * 4 * LN_MAXV, "star_layernorm_bwd: bad M=%d D=%d", M, D);
     int nb = cdiv(M, LN_BWD_THREADS / 64);
@@ -233,4 +233,39 @@ extern "C" int star_layernorm_bwd(const void* dy, const float* x, const float* g
     hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3(cdiv(2 * D, 16)), dim3(1024), 0, (hipStream_t)stream, ws, dgamma, dbeta, nb, D);
     STAR_LAUNCH_CHECK("star_layernorm_bwd(reduce)");
     return 0;
+}
+
+extern "C" int star_layernorm_bwd(const void* dy, const float* x, const float* gamma, const float* mean,
+                                  const float* rstd, const float* g_in, float* g_out, void* g_out_lp, float* dgamma,
+                                  float* dbeta, float* ws, int M, int D, int dt, void* stream) {
+    return ln_bwd_launch(dy, x, gamma, mean, rstd, g_in, g_out, g_out_lp, dgamma, dbeta, ws, M, D, dt, stream);
+}
+
+// ---- the allocation-free variant -------------------------------------------------------------------------------
+// Same kernels as star_layernorm_bwd; the partial dgamma/dbeta rows live in a file-scope device array instead of a
+// caller-provided workspace, for callers that cannot allocate (HIP graph capture, tight serving loops).  One copy of the
+// array per GPU, at its own address: the address is looked up once per device and kept.  Nothing in it has to start at
+// zero (the first kernel writes every partial row the second one reads), so no clearing; calls that overlap on one GPU
+// (two streams) race on it.
+#define LN_STATIC_MAX_D 1024
+#define LN_STATIC_MAX_DEV 64
+static __device__ __align__(256) float scratch[(size_t)LN_BWD_BLOCKS * 2 * LN_STATIC_MAX_D];   // 6 MiB
+static float* volatile g_scratch_ptr[LN_STATIC_MAX_DEV];
+
+extern "C" int star_layernorm_bwd_static(const void* dy, const float* x, const float* gamma, const float* mean,
+                                         const float* rstd, const float* g_in, float* g_out, void* g_out_lp,
+                                         float* dgamma, float* dbeta, int M, int D, int dt, void* stream) {
+    STAR_CHECK(D <= LN_STATIC_MAX_D, "star_layernorm_bwd_static: D=%d exceeds the built-in scratch (D <= %d); use star_layernorm_bwd with a workspace", D, LN_STATIC_MAX_D);
+    int dev = -1;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return star_set_error(-2, "star_layernorm_bwd_static: hipGetDevice: %s", hipGetErrorString(e));
+    STAR_CHECK(dev >= 0 && dev < LN_STATIC_MAX_DEV, "star_layernorm_bwd_static: device %d out of range", dev);
+    float* ptr = g_scratch_ptr[dev];
+    if (ptr == nullptr) {   // once per device, with that device current: every GPU holds its own copy of the array
+        e = hipGetSymbolAddress((void**)&ptr, HIP_SYMBOL(scratch));
+        if (e != hipSuccess || ptr == nullptr)
+            return star_set_error(-2, "star_layernorm_bwd_static: hipGetSymbolAddress: %s", hipGetErrorString(e));
+        g_scratch_ptr[dev] = ptr;
+    }
+    return ln_bwd_launch(dy, x, gamma, mean, rstd, g_in, g_out, g_out_lp, dgamma, dbeta, ptr, M, D, dt, stream);
 }
