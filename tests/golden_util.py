@@ -13,6 +13,12 @@ MODEL_CASES = [
     "small_T2_comp_train", "small_T1_comp_infer",
 ]
 
+# the same reference models after a few hundred AdamW steps on the structured law (gen_golden_trained.py): confident logits
+TRAINED_CASES = [
+    "trained_small_T2_comp_train", "trained_small_T2_comp_infer", "trained_small_T1_comp_infer", "trained_small_T1_comp_train",
+    "trained_tiny_T3_rand_infer", "trained_tiny_T3_rand_train", "trained_tiny_T3_rand90_infer",
+]
+
 DIMS = {
     "tiny": dict(patch=8, chans=13, dim=32, depth=2, heads=2, ddim=32, ddepth=2, dheads=2),
     "small": dict(patch=8, chans=13, dim=64, depth=2, heads=2, ddim=48, ddepth=1, dheads=3),
@@ -34,7 +40,7 @@ class Case:
         self.mask_ratio = float(z["mask_ratio"])
         fl = z["flags"]
         self.flags = dict(encode_partial=bool(fl[0]), no_temp_emb=bool(fl[1]), decode_singletemp=bool(fl[2]))
-        self.dims = dict(DIMS[name.split("_")[0]])
+        self.dims = dict(DIMS[name.replace("trained_", "").split("_")[0]])
         self.bev = torch.from_numpy(unpack(z["bev_bits"], z["bev_shape"]))
         self.next = torch.from_numpy(unpack(z["next_bits"], z["next_shape"])) if self.T > 1 else torch.zeros(self.A * self.B, 0)
         self.teacher = torch.from_numpy(unpack(z["teacher_bits"], z["teacher_shape"]))

@@ -4,7 +4,9 @@
 fp32 compute mode ("the reference's numerics"): logits within 2e-4, loss within 1e-5, occupancy decisions
 and fused maps identical wherever the golden logit margin exceeds 1e-3, identical IoU in that case.
 bf16 compute mode (the throughput mode): logits within 6e-2 absolute, loss within 1 % relative, decisions
-identical wherever the golden margin exceeds 0.25, gradients within 25 % relative Frobenius error per tensor (tiny models: few rows to average over).
+identical wherever the golden margin exceeds 0.03 and on all but 6e-3 of the voxels (random-init weights put half of the voxels
+below a margin of 0.25), per-tensor gradient error <= 6 % of the tensor's norm + 2 % of the whole gradient's norm (measured: <= 1.2 % of the tensor's norm on all but the patch embedding of the encode_partial case, 10 % = 1.5 % of the whole gradient).
+Trained weights (confident logits), both modes: tests/test_trained_gpu.py.
 Mask indices, mask, gather order: bit-exact in both modes."""
 from functools import partial
 
@@ -81,9 +83,10 @@ def test_model_against_golden(name, dtype):
     assert abs(loss.item() - c.loss) < (1e-5 if f32 else 1e-2 * c.loss)
     # ---- decisions, fused maps, IoU ----
     margin = (gp[:, 1] - gp[:, 0]).abs().numpy()
-    safe = margin > (1e-3 if f32 else 0.25)
+    safe = margin > (1e-3 if f32 else 0.03)        # bf16: measured, every flipped voxel has a reference margin < 0.0074
     assert (ind.cpu().numpy() == c.ind)[safe].all()
-    assert safe.mean() > (0.99 if f32 else 0.5)
+    assert safe.mean() > (0.99 if f32 else 0.9)
+    assert (ind.cpu().numpy() != c.ind).mean() <= (0.0 if f32 and safe.all() else 6e-3)   # bf16 measured <= 1.9e-3 (random init: margins ~ 0.25)
     if (ind.cpu().numpy() == c.ind).all():
         assert np.array_equal(result.cpu().numpy(), c.result)
         meter = O.IoUMeter()
@@ -97,6 +100,7 @@ def test_model_against_golden(name, dtype):
     if c.train:
         loss.backward()
         params = dict(m.named_parameters())
+        gall = float(torch.sqrt(sum(g.pow(2).sum() for g in c.grads().values() if g.numel())))
         for k, g in c.grads().items():
             if g.numel() == 0:
                 assert params[k].grad is None, k
@@ -105,9 +109,9 @@ def test_model_against_golden(name, dtype):
             assert mine is not None, k
             if f32:
                 torch.testing.assert_close(mine.cpu(), g, rtol=2e-3, atol=2e-6, msg=lambda s, k=k: k + ": " + s)
-            else:
-                err = (mine.cpu() - g).norm() / (g.norm() + 1e-12)
-                assert err < 0.25 or g.norm() < 1e-7, (k, float(err))
+            else:   # measured worst per-tensor error 1.2 % (tools/measure_bf16_parity.py); gall = norm of the whole gradient
+                err = float((mine.cpu() - g).norm())
+                assert err <= 0.06 * float(g.norm()) + 0.02 * gall, (k, err, float(g.norm()), gall)
 
 
 def test_nchw_contiguous_input_gives_identical_results():

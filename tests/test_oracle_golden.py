@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 import torch
 
-from golden_util import GOLD, MODEL_CASES, Case, unpack
+from golden_util import GOLD, MODEL_CASES, TRAINED_CASES, Case, unpack
 from oracle import c_oracle as OC
 from oracle import star_oracle as O
 
@@ -61,7 +61,7 @@ def test_warp_and_fusion_full_resolution_bit_exact():
     assert np.array_equal(O.late_fusion(ind, trans.astype(np.float32), na, B), unpack(z["late32_bits"], z["shape"]))
 
 
-@pytest.mark.parametrize("name", MODEL_CASES)
+@pytest.mark.parametrize("name", MODEL_CASES + TRAINED_CASES)
 def test_model_case(name):
     c = Case(name)
     cfg = O.make_cfg(img=c.S, T=c.T, mask=c.mask, **c.dims, **c.flags)
