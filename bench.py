@@ -22,6 +22,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_BF16_TFLOPS = 2500.0      # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
+PEAK_F32_TFLOPS = 157.3        # fp32-input MFMA = the fp32 vector rate (same guide)
 PEAK_HBM_GBS = 8000.0
 
 
@@ -51,37 +52,75 @@ _FAMILY_KERNELS = {"gemm_nt": ("void gemm_nt_fast_kernel", "void gemm_nt_wreg_ke
                    "ce_argmax": ("void ce_argmax_",), "warp_fuse": ("warp_fuse_", "wf_pack_bits")}
 
 
-def _pmc_traffic(family):
-    """HBM-side bytes per launch of the family's kernels from the committed PMC summary (tools/pmc_traffic.sh: separate
-    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this same bench command, gfx950 FETCH_SIZE correction applied).
-    Counters cannot be collected inside the timed run, so this is read from profiles/; None if the file is absent."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-    if not os.path.exists(path) or family not in _FAMILY_KERNELS:
+def _pmc_file(name, workload):
+    """A committed PMC summary (tools/pmc_traffic.sh / tools/pmc_mfma.sh over this same bench command), or None when it is
+    absent or was collected for a DIFFERENT workload string: counters cannot be collected inside the timed run, so they are
+    read from profiles/ -- but only for the workload they were measured on."""
+    path = os.path.join(ROOT, "profiles", name)
+    if not os.path.exists(path):
         return None
     with open(path) as f:
-        kernels = json.load(f)["kernels"]
+        d = json.load(f)
+    return d if d.get("workload") == workload else None
+
+
+def _pmc_traffic(family, workload):
+    """HBM-side bytes per launch of the family's kernels (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, gfx950
+    FETCH_SIZE correction applied)."""
+    d = _pmc_file("r02_pmc_traffic.json", workload)
+    if d is None or family not in _FAMILY_KERNELS:
+        return None
     tot, n = 0.0, 0
-    for name, v in kernels.items():
+    for name, v in d["kernels"].items():
         if name.startswith(_FAMILY_KERNELS[family]):
             tot += (v["fetch_bytes_per_launch"] + v["write_bytes_per_launch"]) * v["launches"]
             n += v["launches"] if not name.startswith(("wgrad_reduce", "ln_bwd_reduce", "void attn_delta_", "wf_pack_bits")) else 0
     return round(tot / n) if n else None
 
 
-def _pmc_mfma_util(family):
-    """Fraction of SIMD cycles with the MFMA pipe busy for the family, from the committed PMC summary (tools/pmc_mfma.sh over
-    this same bench command); None if absent."""
-    path = os.path.join(ROOT, "profiles", "r01_l_pmc_mfma.json")
-    if not os.path.exists(path):
+def _pmc_mfma_util(family, workload):
+    """Fraction of SIMD cycles with the MFMA pipe busy for the family (one more --pmc pass)."""
+    d = _pmc_file("r02_pmc_mfma.json", workload)
+    if d is None:
         return None
-    with open(path) as f:
-        v = json.load(f)["families"].get(family)
+    v = d["families"].get(family)
     return round(v["mfma_util_busy_cycles"], 4) if v and v.get("mfma_util_busy_cycles") is not None else None
 
 
-def cpu_baseline(args, cores):
-    """The CPU oracle's training step (fp32 PyTorch-CPU restatement of the reference path + AdamW) on ONE
-    synthetic scene of the same law; 1 warm-up + 2 timed steps (about 10-20 s)."""
+def flops_per_frame(c, mask, mask_ratio, train):
+    """algorithmic FLOPs (2 x MACs) per output frame of the configured model; train = 3 x forward."""
+    import math
+    L, D, Dd, V, T = c.L, c.dim, c.ddim, c.V, c.T
+    keep = int(L * (1 - mask_ratio)) if mask == "random" else math.ceil(L / T)
+
+    def block(dm, l):
+        return 2 * l * 12 * dm * dm + 4 * l * l * dm
+
+    l_enc = keep if c.encode_partial else L
+    enc = 2 * l_enc * V * D + c.depth * block(D, l_enc) + 2 * keep * D * c.inter
+    dec = T * (2 * keep * c.inter * D + 2 * keep * D * Dd) + c.ddepth * block(Dd, L) + 2 * L * Dd * 2 * V
+    return (T * enc + dec) * (3 if train else 1)
+
+
+def _cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(args, cores, budget_s=100.0):
+    """the CPU oracle (fp32 PyTorch-CPU restatement of the reference path, pinned to the reference's goldens)
+    on this box's host cores, same synthetic law: 3 warm-up + 10 timed iterations, median -- the training step (forward +
+    backward + AdamW over timm's groups) and the C1 inference leg (1 scene x 5 agents), each on ONE scene.  `cores` = the
+    threads used: the box's CPU share for one GPU (16; os.cpu_count() shows the whole machine).  Bounded: a leg stops
+    timing early when it has used its half of `budget_s` (the count actually timed is reported)."""
+    import statistics
+
     from oracle import star_oracle as O
     from star_amd.models import multiagent_mae as mm
     from star_amd.synthetic import make_batch
@@ -92,22 +131,42 @@ def cpu_baseline(args, cores):
     cfg = O.make_cfg(img=c.img, patch=c.patch, chans=c.chans, dim=c.dim, depth=c.depth, heads=c.heads, ddim=c.ddim,
                      ddepth=c.ddepth, dheads=c.dheads, T=c.T, mask=c.mask)
     sd = O.trainable(ref.state_dict())
-    named = [(k, v) for k, v in sd.items()]
-    opt = torch.optim.AdamW(O.weight_decay_groups(named, 0.05), lr=1e-3, betas=(0.9, 0.95))
+    opt = torch.optim.AdamW(O.weight_decay_groups(list(sd.items()), 0.05), lr=1e-3, betas=(0.9, 0.95))
     data = make_batch(1, args.agents, args.time_stamp, device="cpu")
     bev = data["bev_seq"].squeeze(1).permute(0, 3, 1, 2).contiguous()
     nxt = data["bev_seq_next"].permute(0, 1, 4, 2, 3).contiguous() if args.time_stamp > 1 else data["bev_seq_next"]
-    times = []
-    for it in range(3):
-        t0 = time.perf_counter()
-        loss, *_ = O.run(sd, cfg, bev, nxt, data["trans_matrices"].numpy(), data["num_agent"].numpy(), 1, mask_ratio=args.mask_ratio)
+    tr, na = data["trans_matrices"].numpy(), data["num_agent"].numpy()
+
+    def train_step():
+        loss = O.run(sd, cfg, bev, nxt, tr, na, 1, mask_ratio=args.mask_ratio)[0]
         loss.backward()
         opt.step()
         opt.zero_grad()
-        times.append(time.perf_counter() - t0)
-    t = sum(times[1:]) / 2
-    return {"value": round(args.agents / t, 3), "unit": "BEV frames/s", "cores": cores, "kind": "port",
-            "sample": "CPU oracle (fp32 PyTorch-CPU) training step incl. AdamW, 1 scene x %d agents, 1 warm-up + 2 timed steps" % args.agents}
+
+    def infer_step():
+        with torch.no_grad():
+            O.run(sd, cfg, bev, nxt, tr, na, 1, mask_ratio=args.mask_ratio, infer=True)
+
+    def timed(fn):
+        t_leg = time.perf_counter()
+        times = []
+        for it in range(13):
+            t0 = time.perf_counter()
+            fn()
+            if it >= 3:
+                times.append(time.perf_counter() - t0)
+            if time.perf_counter() - t_leg > budget_s / 2 and len(times) >= 3:
+                break
+        return statistics.median(times), len(times)
+
+    t_train, n_train = timed(train_step)
+    t_inf, n_inf = timed(infer_step)
+    leg = "train" if args.mode == "train" else "infer"
+    return {"value": round(args.agents / (t_train if leg == "train" else t_inf), 3), "unit": "BEV frames/s", "cores": cores, "kind": "port",
+            "cpu_model": _cpu_model(), "train_frames_per_s": round(args.agents / t_train, 3), "infer_frames_per_s": round(args.agents / t_inf, 3),
+            "sample": "CPU oracle (fp32 PyTorch-CPU, %d threads), 1 scene x %d agents: training step incl. AdamW (median of %d after 3 "
+                      "warm-up) and inference = config C1 (median of %d after 3 warm-up); value = the %s leg"
+                      % (cores, args.agents, n_train, n_inf, leg)}
 
 
 def main():
@@ -183,7 +242,8 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # probe step with every kernel family timed -> pick the dominant one
+    # one plain step (first launches load code objects), then a probe step with every kernel family timed -> the dominant one
+    step()
     ops.PROFILER = ops.Profiler()
     step()
     probe = ops.PROFILER.summary()
@@ -210,50 +270,60 @@ def main():
         elapsed = tmax.item()
     if rank == 0:
         value = frames_per_step * world * args.steps / elapsed
-        peak_f = PEAK_BF16_TFLOPS if args.dtype == "bf16" else 157.3
-        # the resource that bounds the family: time at peak MFMA rate vs time at peak HBM rate for its algorithmic work
-        mfma_bound = prof["flops"] > 0 and prof["flops"] / (peak_f * 1e12) >= prof["bytes"] / (PEAK_HBM_GBS * 1e9)
-        if mfma_bound:
-            ach = prof["flops"] / (prof["ms"] * 1e-3) / 1e12
-            roof = {"kernel": dominant, "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS if args.dtype == "bf16" else 157.3,
-                    "unit": "TFLOP/s", "frac": round(ach / (PEAK_BF16_TFLOPS if args.dtype == "bf16" else 157.3), 4), "traffic": None,
-                    "launches_per_step": prof["launches"] // sampled, "avg_launch_us": round(1e3 * prof["ms"] / prof["launches"], 2),
-                    "share_of_step": round(prof["ms"] / sampled / (1e3 * elapsed / args.steps), 3)}
-        else:
-            ach = prof["bytes"] / (prof["ms"] * 1e-3) / 1e9
-            roof = {"kernel": dominant, "bound": "hbm", "achieved": round(ach, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                    "frac": round(ach / PEAK_HBM_GBS, 4), "traffic": None, "launches_per_step": prof["launches"] // sampled,
-                    "avg_launch_us": round(1e3 * prof["ms"] / prof["launches"], 2),
-                    "share_of_step": round(prof["ms"] / sampled / (1e3 * elapsed / args.steps), 3),
-                    "mfma_tflops": round(prof["flops"] / (prof["ms"] * 1e-3) / 1e12, 1)}
-        roof["timed_launches"] = prof["launches"]     # HIP-event samples inside the timed region (every 4-th step)
-        roof["algorithmic_bytes_per_launch"] = round(prof["bytes"] / prof["launches"])
-        roof["algorithmic_flops_per_launch"] = round(prof["flops"] / prof["launches"])
-        traffic = _pmc_traffic(dominant)
-        if traffic is not None:
-            roof["traffic"] = traffic
-        util = _pmc_mfma_util(dominant)
+        peak_f = PEAK_BF16_TFLOPS if args.dtype == "bf16" else PEAK_F32_TFLOPS
+
+        def roofline_of(tag, v, samples=None):
+            """Roofline entry of one kernel family from its HIP-event times: the bound is whichever of flops/peak and
+            bytes/peak is the longer time for its ALGORITHMIC work (every operand and result once)."""
+            mfma_bound = v["flops"] > 0 and v["flops"] / (peak_f * 1e12) >= v["bytes"] / (PEAK_HBM_GBS * 1e9)
+            tf = v["flops"] / (v["ms"] * 1e-3) / 1e12
+            gb = v["bytes"] / (v["ms"] * 1e-3) / 1e9
+            r = {"kernel": tag, "bound": "mfma" if mfma_bound else "hbm", "achieved": round(tf, 2) if mfma_bound else round(gb, 1),
+                 "peak": peak_f if mfma_bound else PEAK_HBM_GBS, "unit": "TFLOP/s" if mfma_bound else "GB/s",
+                 "frac": round(tf / peak_f, 4) if mfma_bound else round(gb / PEAK_HBM_GBS, 4), "traffic": None,
+                 "avg_launch_us": round(1e3 * v["ms"] / v["launches"], 2), "mfma_tflops": round(tf, 1), "hbm_gbs": round(gb, 1),
+                 "algorithmic_bytes_per_launch": round(v["bytes"] / v["launches"]), "algorithmic_flops_per_launch": round(v["flops"] / v["launches"])}
+            if samples:
+                r["launches_per_step"] = v["launches"] // samples
+                r["timed_launches"] = v["launches"]      # HIP-event samples inside the timed region (every 4-th step)
+                r["share_of_step"] = round(v["ms"] / samples / (1e3 * elapsed / args.steps), 3)
+            return r
+
+        workload = "STAR completion %s step, %s, batch %d scenes x %d agents per GPU, 256x256x13 BEV, T=%d, %s mask%s" % (
+            args.mode, args.model, args.batch, args.agents, args.time_stamp, args.mask,
+            " ratio %.2f" % args.mask_ratio if args.mask == "random" else " (ratio 1-1/T: mask_ratio is ignored, reference Q1)")
+        roof = roofline_of(dominant, prof, sampled)
+        roof["traffic"] = _pmc_traffic(dominant, workload)            # null unless measured for THIS workload
+        util = _pmc_mfma_util(dominant, workload)
         if util is not None:
             roof["mfma_util_pmc"] = util
+        # every family of the probe step (one step, event pair per launch, side stream included), largest first
+        families = [roofline_of(k, v) for k, v in sorted(probe.items(), key=lambda kv: -kv[1]["ms"]) if v["ms"] > 0]
+        for f_, (k, v) in zip(families, sorted(probe.items(), key=lambda kv: -kv[1]["ms"])):
+            f_["launches_per_step"], f_["ms_per_step"] = v["launches"], round(v["ms"], 3)
         if args.profile_all:
             tot = sum(v["ms"] for v in probe.values())
             for k, v in sorted(probe.items(), key=lambda kv: -kv[1]["ms"]):
                 print("  %-14s %4d launches %8.3f ms (%4.1f%%) %8.1f TFLOP/s %8.1f GB/s" % (
                     k, v["launches"], v["ms"], 100 * v["ms"] / tot, v["flops"] / (v["ms"] * 1e-3 + 1e-12) / 1e12,
                     v["bytes"] / (v["ms"] * 1e-3 + 1e-12) / 1e9), file=sys.stderr)
+        fpf = flops_per_frame(model._cfg(), args.mask, args.mask_ratio, args.mode == "train")
         out = {
             "metric": "BEV frames/sec (5-agent scenes, %s)" % ("train" if args.mode == "train" else "infer"),
             "value": round(value, 2), "unit": "BEV frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": "STAR completion %s step, %s, batch %d scenes x %d agents per GPU, 256x256x13 BEV, T=%d %s mask"
-                       % (args.mode, args.model, args.batch, args.agents, args.time_stamp, args.mask),
+            "config": {"workload": workload,
                        "global_batch_scenes": args.batch * world, "frames_per_step": frames_per_step * world,
                        "parallelism": "dp%d (scene-sharded, RCCL grad all-reduce)" % world if world > 1 else "single GPU",
                        "loss": round(float(loss), 6)},
             "roofline": roof,
+            # SURVEY 8(d): the whole step against the MFMA peak = frames/s x algorithmic FLOP per frame / (N x peak)
+            "step_roofline": {"gflop_per_frame": round(fpf / 1e9, 2), "achieved_tflops": round(value * fpf / 1e12 / world, 1),
+                              "peak_tflops": peak_f, "frac_of_mfma_peak": round(value * fpf / 1e12 / world / peak_f, 4)},
+            "families": families[:6],
         }
-        if world == 1 and not args.no_cpu_baseline and args.mode == "train" and args.com == "ind_mae":
+        if world == 1 and not args.no_cpu_baseline and args.com == "ind_mae":
             out["cpu_baseline"] = cpu_baseline(args, min(16, os.cpu_count() or 1))
         print(json.dumps(out), flush=True)
     if world > 1:

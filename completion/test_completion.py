@@ -19,7 +19,21 @@ from star_amd.synthetic import make_batch  # noqa: E402
 
 
 def main(args):
-    device = torch.device("cuda")
+    world, rank, local = int(os.environ.get("WORLD_SIZE", 1)), int(os.environ.get("RANK", 0)), int(os.environ.get("LOCAL_RANK", 0))
+    if world > 1:
+        # replicas only: rank r evaluates batches r, r + world, ...; the per-batch IoUs are gathered to every rank and averaged
+        # in batch order, so the result is the single-process one bit for bit (the reference averages PER-BATCH IoUs,
+        # star/utils/metrics.py:210-218, so summing confusion matrices over ranks would give a different number)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        backend = os.environ.get("STAR_AMD_DIST_BACKEND", "nccl")     # "gloo": rehearsal with ranks that share one GPU
+        local = local % torch.cuda.device_count()
+        torch.cuda.set_device(local)
+        if backend == "nccl":
+            torch.distributed.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            torch.distributed.init_process_group(backend)
+    device = torch.device("cuda", local)
+    torch.manual_seed(args.seed)       # without --resume the weights are random: at least the same ones in every process
     num_agent = args.num_agent - 1 if args.no_cross_road else args.num_agent
     if args.com == "vqstar":    # reference test_completion.py:108-113
         model = VQSTAR.vqstar(norm_pix_loss=args.norm_pix_loss, time_stamp=args.time_stamp, mask_method=args.mask, decay=args.decay,
@@ -42,10 +56,14 @@ def main(args):
         args.iters = dataset.steps_per_epoch(args.batch)
         batches = dataset.loader(args.batch, shuffle=False, num_workers=args.nworker, device=device)
     else:
-        batches = ((make_batch(args.batch, num_agent, args.time_stamp, seed=10_000 + it, device=device), args.batch) for it in range(args.iters))
+        batches = ((it, make_batch(args.batch, num_agent, args.time_stamp, seed=10_000 + it, device=device), args.batch)
+                   for it in range(args.iters) if it % world == rank)
     evaluator = Metrics(2, args.iters)
-    losses = 0.0
-    for data, bsz in batches:
+    losses = []
+    if args.data != "synthetic":
+        batches = ((it,) + tuple(b) for it, b in enumerate(batches) if it % world == rank)
+    for it, data, bsz in batches:
+        torch.manual_seed(args.seed + it)        # the mask noise of batch `it` does not depend on which rank evaluates it
         if args.com == "vqstar":
             loss, reconstruction, ind_pred, perplexity, encodings = co_module.infer_vqstar_completion(data, bsz, args.mask_ratio)
         else:
@@ -53,10 +71,23 @@ def main(args):
         teacher = data["bev_seq_teacher"].squeeze(1).permute(0, 3, 1, 2)
         evaluator.add_batch(reconstruction, teacher.contiguous())
         evaluator.update_IoU()
-        losses += loss
+        losses.append(loss)
+    if world > 1:
+        mine = [(rank + i * world, iou, l) for i, (iou, l) in enumerate(zip(evaluator.every_batch_IoU, losses))]
+        parts = [None] * world
+        torch.distributed.all_gather_object(parts, mine)
+        rows = sorted((r for p in parts for r in p), key=lambda r: r[0])
+        evaluator.every_batch_IoU = [r[1] for r in rows]
+        losses = [r[2] for r in rows]
     iou = evaluator.get_average_IoU()
-    print("Average loss {:.6f}".format(losses / args.iters))
-    print("Occupancy IoU  scale 1: {:.6f}  scale 1/2: {:.6f}  scale 1/4: {:.6f}".format(*iou))
+    if rank == 0:
+        if args.verbose:
+            for i, (v, l) in enumerate(zip(evaluator.every_batch_IoU, losses)):
+                print("batch {}: loss {:.9f} IoU {:.9f} {:.9f} {:.9f}".format(i, l, *v))
+        print("Average loss {:.6f}".format(sum(losses) / len(losses)))
+        print("Occupancy IoU  scale 1: {:.9f}  scale 1/2: {:.9f}  scale 1/4: {:.9f}".format(*iou))
+    if world > 1:
+        torch.distributed.destroy_process_group()
     return iou
 
 
@@ -81,4 +112,6 @@ if __name__ == "__main__":
     p.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     p.add_argument("--iters", default=10, type=int, help="synthetic batches to evaluate")
     p.add_argument("--nworker", default=2, type=int)
+    p.add_argument("--verbose", action="store_true", help="print every batch's loss and IoU")
+    p.add_argument("--seed", default=0, type=int, help="mask-noise seed (random masking draws noise at inference too)")
     main(p.parse_args())

@@ -50,9 +50,15 @@ def main(args):
     world, rank, local = int(os.environ.get("WORLD_SIZE", 1)), int(os.environ.get("RANK", 0)), int(os.environ.get("LOCAL_RANK", 0))
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        backend = os.environ.get("STAR_AMD_DIST_BACKEND", "nccl")     # "gloo": rehearsal with ranks that share one GPU
+        local = local % torch.cuda.device_count()
         torch.cuda.set_device(local)
-        torch.distributed.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            torch.distributed.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            torch.distributed.init_process_group(backend)
     device = torch.device("cuda", local)
+    torch.manual_seed(args.seed)                     # the same initial weights on every rank (rank 0's are broadcast anyway)
     if args.com not in ("ind_mae", "vqstar"):
         raise ValueError("com: %s is not supported by the MI355X path (use ind_mae or vqstar)" % args.com)
     num_agent = args.num_agent - 1 if args.no_cross_road else args.num_agent
@@ -80,6 +86,7 @@ def main(args):
                      torch.optim.AdamW(add_weight_decay(model, args.weight_decay), lr=args.lr, betas=(0.9, 0.95)))
         parallel = None
     co_module = CoModule(model, optimizer, args.com, parallel=parallel)
+    torch.manual_seed(args.seed * 1000003 + rank)    # mask noise (and the EMA seeding's shuffle): every rank its own stream
 
     cross = "no_cross" if args.no_cross_road else "with_cross"
     model_save_path = check_folder(os.path.join(args.logpath or "logs", args.com, cross))
@@ -190,6 +197,7 @@ if __name__ == "__main__":
     p.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     p.add_argument("--iters_per_epoch", default=100, type=int, help="synthetic batches per epoch")
     p.add_argument("--no_fused_optimizer", dest="fused_optimizer", action="store_false")
+    p.add_argument("--seed", default=0, type=int)
     a = p.parse_args()
     print(a)
     main(a)

@@ -53,11 +53,23 @@ class STARVectorQuantizerEMA(nn.Module):
     def initialize_from(self, latent):
         """mae_base.py:200-208: k-means (scipy kmeans2, minit="points") over the shuffled latent rows of the first
         training batch seeds `_ema_w`; runs once, on the host, like the reference's."""
-        from scipy.cluster.vq import kmeans2
-        flat = latent.detach().reshape(-1, self._embedding_dim)
-        rp = torch.randperm(flat.size(0), device=flat.device)
-        centers, _ = kmeans2(flat[rp].cpu().numpy(), self._num_embeddings, minit="points")
-        self._ema_w.data.copy_(torch.from_numpy(centers).to(self._ema_w.dtype))
+        import torch.distributed as dist
+        multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        if not multi or dist.get_rank() == 0:
+            from scipy.cluster.vq import kmeans2
+            flat = latent.detach().reshape(-1, self._embedding_dim)
+            rp = torch.randperm(flat.size(0), device=flat.device)
+            centers, _ = kmeans2(flat[rp].cpu().numpy(), self._num_embeddings, minit="points")
+            self._ema_w.data.copy_(torch.from_numpy(centers).to(self._ema_w.dtype))
+        if multi:
+            # data-parallel replicas must start from ONE seeding (rank 0's scenes): every rank has its own latents, its own
+            # randperm and its own k-means run, and nothing else ever synchronises `_ema_w` (it is no optimizer parameter)
+            if dist.get_backend() == "nccl" or not self._ema_w.is_cuda:
+                dist.broadcast(self._ema_w.data, 0)
+            else:
+                host = self._ema_w.data.cpu()
+                dist.broadcast(host, 0)
+                self._ema_w.data.copy_(host)
         self.data_initialized = 1
 
 

@@ -55,18 +55,28 @@ class CoModule(object):
             # The loss is copied to pinned host memory right behind the forward kernels, THEN the whole backward (and the
             # bucketed gradient all-reduce) is enqueued; the host waits for the copy only, so the finite check still precedes
             # the update while the GPU never idles on a round trip -- the optimizer launch is queued behind the backward.
+            # Multi-rank: the ranks must take the stop/continue decision TOGETHER (a rank that exits alone leaves the others
+            # blocked in the gradient all-reduce): a one-word MAX all-reduce of "my loss is not finite" rides between forward
+            # and backward on RCCL's stream and comes back in the same pinned copy as the loss.
             if self._loss_host is None:
-                self._loss_host = torch.empty((), dtype=torch.float32).pin_memory()
+                self._loss_host = torch.zeros(2, dtype=torch.float32).pin_memory()
                 self._loss_event = torch.cuda.Event()
-            self._loss_host.copy_(loss.detach(), non_blocking=True)
+            flag = self.parallel.nonfinite_flag(loss) if self.parallel is not None else None
+            self._loss_host[0:1].copy_(loss.detach().reshape(1), non_blocking=True)
+            if flag is not None:
+                self._loss_host[1:2].copy_(flag, non_blocking=True)
             self._loss_event.record()
             loss.backward()
             self._loss_event.synchronize()
-            loss_value = float(self._loss_host)
+            loss_value = float(self._loss_host[0])
+            bad = not math.isfinite(loss_value) or (flag is not None and float(self._loss_host[1]) > 0)
+            if self.parallel is not None and flag is None:
+                bad = self.parallel.any_rank(bad)                  # gloo rehearsal: agreed on the host
         else:
             loss_value = loss.item()
-        if not math.isfinite(loss_value):
-            print("Loss is {}, stopping training".format(loss_value))
+            bad = not math.isfinite(loss_value)
+        if bad:
+            print("Loss is {}, stopping training".format(loss_value))      # on every rank in the same step (reference: CoModule.py:116-122)
             sys.exit(1)
         if fused:
             if self.parallel is not None:

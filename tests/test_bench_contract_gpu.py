@@ -29,8 +29,14 @@ def test_bench_line_train():
     r = j["roofline"]
     assert r["bound"] in ("hbm", "mfma") and r["unit"] in ("GB/s", "TFLOP/s") and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
     assert r["timed_launches"] > 0 and r["avg_launch_us"] > 0 and (r["traffic"] is None or r["traffic"] > 0)
+    assert r["traffic"] is None or "mask" in j["config"]["workload"]      # PMC numbers only for the workload they were measured on
+    s = j["step_roofline"]      # frames/s x FLOP/frame / peak
+    assert abs(s["gflop_per_frame"] - 131.77) < 0.1 and abs(s["frac_of_mfma_peak"] - j["value"] * 131.77e9 / 2.5e15) < 2e-3
+    fam = {f["kernel"] for f in j["families"]}
+    assert {"gemm_nt", "gemm_wgrad", "attn_bwd"} <= fam
     c = j["cpu_baseline"]
-    assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and c["sample"]
+    assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and c["sample"] and c["cpu_model"]
+    assert c["value"] == c["train_frames_per_s"] and c["infer_frames_per_s"] > c["train_frames_per_s"]
 
 
 def test_bench_line_infer_has_no_cpu_leg():

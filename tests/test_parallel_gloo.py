@@ -22,7 +22,9 @@ def _fake_optimizer(model):
         n = sum((named[k].numel() + 3) // 4 * 4 for k in st)
         ranges.append((off, off + n))
         off += n
-    return types.SimpleNamespace(is_star_flat=True, stage_ranges=ranges, flat_g=torch.zeros(off), flat_p=torch.zeros(off), total=off)
+    offsets = {k: 0 for st in stages for k in st}      # names that live in the flat buffer (the values are not used here)
+    return types.SimpleNamespace(is_star_flat=True, stage_ranges=ranges, flat_g=torch.zeros(off), flat_p=torch.zeros(off), total=off,
+                                 offsets=offsets)
 
 
 def _worker(rank, world, port, out):
@@ -36,8 +38,13 @@ def _worker(rank, world, port, out):
     assert model._on_grads_ready is not None and not par.native_avg
     # parameters: rank 0's copy wins
     opt.flat_p.fill_(float(rank + 1))
+    with torch.no_grad():      # state outside the flat buffer (frozen tables, parameters no optimizer owns) travels too
+        model.pos_embed.fill_(float(rank + 5))
+        model.cls_token.fill_(float(rank + 7))
     par.broadcast_parameters(0)
-    assert torch.all(opt.flat_p == 1.0)
+    assert torch.all(opt.flat_p == 1.0) and torch.all(model.pos_embed == 5.0) and torch.all(model.cls_token == 7.0)
+    # the stop/continue decision is taken together: one rank's non-finite loss stops every rank
+    assert par.any_rank(rank == 1) is True and par.any_rank(False) is False
     # gradients: stage k of rank r holds r + k; the callbacks fire in backward order, as the engine does
     for k, (lo, hi) in enumerate(opt.stage_ranges):
         opt.flat_g[lo:hi] = rank + k
@@ -76,3 +83,26 @@ def test_stage_list_covers_every_trainable_parameter_that_gets_a_gradient():
         assert set(names) <= trainable
         never = trainable - set(names)
         assert {"cls_token", "temp_embed"} <= never and never <= {"cls_token", "temp_embed", "mask_token", "decoder_temp_embed"}
+
+
+def _ema_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from star_amd.models.VQSTAR import STARVectorQuantizerEMA
+    torch.manual_seed(100 + rank)                      # every rank: its own scenes, its own randperm
+    vq = STARVectorQuantizerEMA(16, 8, 0.25, 0.99)
+    vq.initialize_from(torch.randn(4, 50, 8) + rank)
+    mine = vq._ema_w.data.clone()
+    ref = mine.clone()
+    dist.broadcast(ref, 0)
+    out[rank] = bool(torch.equal(mine, ref)) and vq.data_initialized == 1 and bool(mine.abs().sum() > 0)
+    dist.destroy_process_group()
+
+
+def test_ema_codebook_seeding_is_rank_zeros_on_every_rank():
+    """every data-parallel replica must start the EMA codebook from ONE k-means seeding."""
+    world = 2
+    with mp.Manager() as mgr:
+        out = mgr.dict()
+        mp.spawn(_ema_worker, args=(world, 29541, out), nprocs=world, join=True)
+        assert dict(out) == {0: True, 1: True}
