@@ -209,7 +209,10 @@ class _SideStream:
 
     def __init__(self, device):
         self.device = device
-        self.stream = _SideStream.streams.setdefault(device, torch.cuda.Stream(device=device))
+        if device not in _SideStream.streams:
+            prio = os.environ.get("STAR_AMD_SIDE_PRIO")
+            _SideStream.streams[device] = torch.cuda.Stream(device=device) if prio is None else torch.cuda.Stream(device=device, priority=int(prio))
+        self.stream = _SideStream.streams[device]
         self.used = False
 
     def run(self, fn, *tensors):
@@ -229,8 +232,15 @@ class _SideStream:
             self.used = False
 
 
+_SKIP_WGRAD = os.environ.get("STAR_AMD_SKIP_WGRAD", "0") == "1"   # measurement only (wrong gradients): the backward chain without its weight-gradient GEMMs
+
+
 def _wg(grads, G, name, dy, x, x_rows=None, side=None):
     """weight + bias gradient of Linear `name`, written into the caller's gradient views when given."""
+    if _SKIP_WGRAD and G is not None:
+        grads[name + ".weight"], grads[name + ".bias"] = G[name + ".weight"], G[name + ".bias"]
+        return
+
     def run():
         return ops.gemm_wgrad(dy, x, x_rows=x_rows, dw=None if G is None else G[name + ".weight"],
                               db=None if G is None else G[name + ".bias"])
