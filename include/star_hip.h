@@ -275,6 +275,40 @@ int star_vq_ema_update(const int32_t* counts, const float* dw, float* codebook, 
                        int E, int K, double decay, double epsilon, void* stream);
 int star_onehot_rows(const int64_t* idx, float* out, int M, int K, void* stream);
 
+/* ---- next row f-1: the joint (latent-level fusion) variant, AmortizedFusionMMAEViT ---------------------------------
+ * Everything channels-last: token rows [N*H*W, C] are the NHWC feature map; the 3x3 convolutions of the conv head run as
+ * nine row-gathered star_gemm taps (a_rows = the shifted-pixel table, -1 = zero padding) accumulating through `res`.
+ * star_feat_warp_fuse replaces forward_fusion's loop (star/models/multiagent_mae.py:497-551): for every scene b and ego
+ *   slot i < num_agent[b,0], out = threshold(feat_i + sum_{j != i} warp_{j->i}(feat_j)) with feature_transformation's two
+ *   nearest resamples at the G x G token grid (star/models/mae_base.py:589-614) and fusion("sum")'s threshold
+ *   (mae_base.py:624-633: >= 0.5 -> 1, < 0.5 -> 0); slots >= num_agent keep feat.  `pos` [G*G, D] (decoder_pos_embed, added in
+ *   forward_decoder :585) is added to every output row when given.  passthrough uint8 [A*B]: 1 where the slot kept its
+ *   own features (the only rows a gradient passes through: the thresholded rows are constants).
+ *   feat/out float32 [A*B, G*G, D], agent-major. */
+int star_feat_warp_fuse(const float* feat, const float* theta, const void* num_agent, int num_agent_is64, const float* pos,
+                        float* out, uint8_t* passthrough, int B, int A, int G, int D, void* stream);
+/* F.interpolate(scale_factor=2, mode='bilinear') of ConvPred (mae_base.py:40,44,48), channels-last [N,H,W,C] -> [N,2H,2W,C]
+ * in `dt`, and its adjoint on float32 gradients (gather form, deterministic).  C % 4 == 0. */
+int star_upsample2x_fwd(const void* x, void* y, int N, int H, int W, int C, int dt, void* stream);
+int star_upsample2x_bwd(const float* dy, float* dx, int N, int H, int W, int C, void* stream);
+/* nn.BatchNorm2d of ConvPred (mae_base.py:27-35) over rows [R = N*H*W, ld] (ld % 4 == 0; pad columns carry zeros):
+ * star_bn_stats: per-column mean, biased variance (two passes) and rstd = 1/sqrt(var + eps); ws float32 [star_bn_ws(ld)].
+ * star_bn_apply: y = (x - mean) * rstd * gamma + beta, optional ReLU (F.relu(self.bnK(...))), y in `dt`.
+ * star_bn_bwd:   backward of that pair; dy float32, dx in `dt`; dgamma / dbeta written; training = batch statistics. */
+int64_t star_bn_ws(int ld);
+int star_bn_stats(const float* x, int64_t R, int ld, float eps, float* mean, float* var, float* rstd, float* ws, void* stream);
+int star_bn_apply(const float* x, const float* mean, const float* rstd, const float* gamma, const float* beta, int relu, int64_t R,
+                  int ld, void* y, int dt, void* stream);
+int star_bn_bwd(const float* x, const float* dy, const float* mean, const float* rstd, const float* gamma, const float* beta,
+                int relu, int training, int64_t R, int ld, void* dx, int dt, float* dgamma, float* dbeta, float* ws, void* stream);
+/* CrossEntropyLoss over stack((free, occ), 1) + argmax(softmax) of the joint model (multiagent_mae.py:598-605,655-681) on
+ * the two heads' channels-last outputs [N*H*W, ld] (C <= ld valid).  target: float image with element strides st[4] =
+ * (n, c, h, w).  ind int64 [N,C,H,W]; pred float32 [N,2,C,H,W] (the tensor the reference returns); dfree / docc float32
+ * [N*H*W, ld] = (softmax - onehot) / (N*C*H*W); loss_partial float32 [star_ce_nhwc_blocks()] -> star_ce_finish. */
+int star_ce_nhwc_blocks(int N, int H, int W);
+int star_ce_nhwc(const float* lfree, const float* locc, const float* target, const int64_t* st, int64_t* ind, float* pred, float* dfree,
+                 float* docc, float* loss_partial, int N, int C, int H, int W, int ld, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

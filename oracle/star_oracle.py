@@ -496,12 +496,101 @@ def run(sd, cfg, imgs1, imgs_next, trans, num_agent, batch, mask_ratio=0.75, inf
     return loss, torch.from_numpy(fused), latent, ind, pred
 
 
+# ---- next row f-1: the joint (latent-level fusion) model -------------------------------------------------------------
+def joint_random_unmasking(x, mask, ids_restore, T, temp_embed, mask_token):
+    """AmortizedFusionMMAEViT.amortized_random_unmasking (multiagent_mae.py:399-441): as the individual model's, but the
+    temporal embedding is always added and the result stays channels-LAST [BA, L, Dd] (no transposed re-read)."""
+    return random_unmasking(x, mask, ids_restore, T, temp_embed, mask_token, False, False).permute(0, 2, 1)
+
+
+def fusion_sum(feat, trans, num_agent, batch):
+    """forward_fusion's loop (multiagent_mae.py:497-551) with fusion("sum") (mae_base.py:624-633): feat [A*B, Dd, g, g];
+    ego + warped neighbours summed in list order, then >= 0.5 -> 1, < 0.5 -> 0 by masked assignment (no gradient passes);
+    slots >= num_agent keep their features (gradient passes)."""
+    ab = feat.shape[0]
+    A = ab // batch
+    out = []
+    det = feat.detach().numpy()
+    for i in range(A):
+        for b in range(batch):
+            n = int(num_agent[b, 0])
+            if i >= n:
+                out.append(feat[i * batch + b])
+                continue
+            acc = det[i * batch + b].copy()
+            for j in range(n):
+                if j != i:
+                    acc = acc + warp_map(det[j * batch + b], trans[b, i, j])
+            fused = acc.copy()
+            fused[acc >= 0.5] = 1.0
+            fused[acc < 0.5] = 0.0
+            out.append(torch.from_numpy(fused.astype(F32)))
+    return torch.stack(out)
+
+
+def conv_pred(x, sd, pre, training, new_stats=None):
+    """ConvPred / ConvPred16 (mae_base.py:16-105): (bilinear x2, conv 3x3 pad 1, BatchNorm, ReLU) per stage, no ReLU after
+    the last.  new_stats (dict) receives the running statistics a training forward leaves behind."""
+    s = 1
+    while (pre + "conv%d.weight" % s) in sd:
+        last = (pre + "conv%d.weight" % (s + 1)) not in sd
+        x = F.interpolate(x, scale_factor=2, mode="bilinear")
+        x = F.conv2d(x, sd[pre + "conv%d.weight" % s], sd[pre + "conv%d.bias" % s], padding=1)
+        rm, rv = sd[pre + "bn%d.running_mean" % s].detach().clone(), sd[pre + "bn%d.running_var" % s].detach().clone()
+        x = F.batch_norm(x, rm, rv, sd[pre + "bn%d.weight" % s], sd[pre + "bn%d.bias" % s], training, 0.1, 1e-5)
+        if new_stats is not None:
+            new_stats[pre + "bn%d.running_mean" % s], new_stats[pre + "bn%d.running_var" % s] = rm, rv
+        if not last:
+            x = F.relu(x)
+        s += 1
+    return x
+
+
+def run_joint(sd, cfg, imgs1, imgs_next, teacher, trans, num_agent, batch, mask_ratio=0.75, noise=None, training=True, taps=None):
+    """AmortizedFusionMMAEViT.forward (multiagent_mae.py:659-681) -> (loss, result int64, mask, pred [BA,2,C,H,W])."""
+    T, g = cfg["T"], cfg["img"] // cfg["patch"]
+    latent, mask, ids_restore = encode(sd, cfg, imgs1, imgs_next, mask_ratio, noise)
+    x = F.linear(latent, sd["decompressor.weight"], sd["decompressor.bias"])
+    x = F.linear(x, sd["decoder_embed.weight"], sd["decoder_embed.bias"])
+    if cfg["mask"] == "complement":
+        x = complement_unmasking(x, ids_restore, T, sd["decoder_temp_embed"], sd["mask_token"], False, False)
+    else:
+        x = joint_random_unmasking(x, mask, ids_restore, T, sd["decoder_temp_embed"], sd["mask_token"])
+    ba, L, dd = x.shape
+    if taps is not None:
+        taps["feat"] = x
+    fused = fusion_sum(x.reshape(ba, g, g, dd).permute(0, 3, 1, 2), np.asarray(trans), np.asarray(num_agent), batch)
+    x = fused.permute(0, 2, 3, 1).reshape(ba, L, dd)
+    if taps is not None:
+        taps["fused"] = x
+    x = x + sd["decoder_pos_embed"][:, 1:]
+    for i in range(cfg["ddepth"]):
+        x = block(x, sd, "decoder_blocks.%d." % i, cfg["dheads"], cfg["eps"])
+    x = F.layer_norm(x, (dd,), sd["decoder_norm.weight"], sd["decoder_norm.bias"], cfg["eps"])
+    if taps is not None:
+        taps["dec_norm"] = x
+    x = x.reshape(ba, g, g, dd).permute(0, 3, 1, 2).contiguous()
+    stats = {} if taps is not None else None
+    occ = conv_pred(x, sd, "decoder_pred_occ.", training, stats)
+    free = conv_pred(x, sd, "decoder_pred_free.", training, stats)
+    if taps is not None:
+        taps["bn_stats"] = stats
+    pred = torch.stack((free, occ), dim=1)
+    loss = F.cross_entropy(pred, teacher.long())
+    result = torch.argmax(torch.softmax(pred.detach(), dim=1), dim=1)
+    return loss, result, mask, pred
+
+
 def trainable(sd):
     """Clone a state dict into leaf tensors; the two sin-cos tables stay frozen (mae_base.py:273,306)."""
     out = {}
     for k, v in sd.items():
-        t = torch.as_tensor(v).detach().clone().float()
-        t.requires_grad_(k not in ("pos_embed", "decoder_pos_embed"))
+        t = torch.as_tensor(v).detach().clone()
+        if not t.is_floating_point():          # BatchNorm's num_batches_tracked
+            out[k] = t
+            continue
+        t = t.float()
+        t.requires_grad_(k not in ("pos_embed", "decoder_pos_embed") and "running_" not in k)
         out[k] = t
     return out
 

@@ -74,6 +74,15 @@ _SIGS = {
     "star_vq_bwd": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _I, _P]),
     "star_onehot_rows": (C.c_int, [_P, _P, _I, _I, _P]),
     "star_voxel_scatter": (C.c_int, [_P, _I, _P, _P, _L, _P, _I, _I, _I, _I, _I, _P, _P]),
+    "star_feat_warp_fuse": (C.c_int, [_P, _P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "star_upsample2x_fwd": (C.c_int, [_P, _P, _I, _I, _I, _I, _I, _P]),
+    "star_upsample2x_bwd": (C.c_int, [_P, _P, _I, _I, _I, _I, _P]),
+    "star_bn_ws": (C.c_int64, [_I]),
+    "star_bn_stats": (C.c_int, [_P, _L, _I, _F, _P, _P, _P, _P, _P]),
+    "star_bn_apply": (C.c_int, [_P, _P, _P, _P, _P, _I, _L, _I, _P, _I, _P]),
+    "star_bn_bwd": (C.c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _L, _I, _P, _I, _P, _P, _P, _P]),
+    "star_ce_nhwc_blocks": (C.c_int, [_I, _I, _I]),
+    "star_ce_nhwc": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
 }
 EXPORTS = tuple(_SIGS)
 

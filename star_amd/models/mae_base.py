@@ -7,7 +7,46 @@ import torch
 import torch.nn as nn
 
 from ..utils.pos_embed import get_2d_sincos_pos_embed
-from .vit import Block, PatchEmbed
+from .vit import Block, PatchEmbed, _no_forward
+
+
+class ConvPred(nn.Module):
+    """Parameter container of the conv prediction head for patch 8 (reference mae_base.py:16-54): conv1/bn1 (C -> C/2),
+    conv2/bn2 (-> C/4), conv3/bn3 (-> output_chans), every conv 3x3 pad 1, each behind a bilinear x2.  The arithmetic runs in
+    star_amd.joint (channels-last, nine GEMM taps per convolution)."""
+
+    def __init__(self, input_size=32, output_size=256, input_chans=512, output_chans=13):
+        super().__init__()
+        chans1 = input_chans // 2
+        self.conv1 = nn.Conv2d(input_chans, chans1, kernel_size=3, stride=1, padding=1)
+        self.bn1 = nn.BatchNorm2d(chans1)
+        chans2 = chans1 // 2
+        self.conv2 = nn.Conv2d(chans1, chans2, kernel_size=3, stride=1, padding=1)
+        self.bn2 = nn.BatchNorm2d(chans2)
+        self.conv3 = nn.Conv2d(chans2, output_chans, kernel_size=3, stride=1, padding=1)
+        self.bn3 = nn.BatchNorm2d(output_chans)
+
+    forward = _no_forward
+
+
+class ConvPred16(nn.Module):
+    """The same for patch 16 (reference mae_base.py:56-105): four stages, C -> C/2 -> C/4 -> C/8 -> output_chans."""
+
+    def __init__(self, input_size=16, output_size=256, input_chans=512, output_chans=13):
+        super().__init__()
+        chans1 = input_chans // 2
+        self.conv1 = nn.Conv2d(input_chans, chans1, kernel_size=3, stride=1, padding=1)
+        self.bn1 = nn.BatchNorm2d(chans1)
+        chans2 = chans1 // 2
+        self.conv2 = nn.Conv2d(chans1, chans2, kernel_size=3, stride=1, padding=1)
+        self.bn2 = nn.BatchNorm2d(chans2)
+        chans3 = chans2 // 2
+        self.conv3 = nn.Conv2d(chans2, chans3, kernel_size=3, stride=1, padding=1)
+        self.bn3 = nn.BatchNorm2d(chans3)
+        self.conv4 = nn.Conv2d(chans3, output_chans, kernel_size=3, stride=1, padding=1)
+        self.bn4 = nn.BatchNorm2d(output_chans)
+
+    forward = _no_forward
 
 
 class MultiAgentMaskedAutoencoderViT(nn.Module):
@@ -15,8 +54,7 @@ class MultiAgentMaskedAutoencoderViT(nn.Module):
                  decoder_embed_dim=512, decoder_depth=8, decoder_num_heads=16, mlp_ratio=4., norm_layer=nn.LayerNorm,
                  decoder_head="mlp", norm_pix_loss=False, time_stamp=1, mask_method="random", inter_emb_dim=32):
         super().__init__()
-        if decoder_head != "mlp":
-            # the conv3 head belongs to the joint-fusion variants (SURVEY.md section 8f "next"), not to this path
+        if decoder_head not in ("mlp", "conv3"):
             raise NotImplementedError("decoder head", decoder_head)
         # ---- encoder ----
         self.patch_embed = PatchEmbed(img_size, patch_size, in_chans, embed_dim)
@@ -38,8 +76,17 @@ class MultiAgentMaskedAutoencoderViT(nn.Module):
         self.decoder_blocks = nn.ModuleList([Block(decoder_embed_dim, decoder_num_heads, mlp_ratio, qkv_bias=True, qk_scale=None,
                                                    norm_layer=norm_layer) for _ in range(decoder_depth)])
         self.decoder_norm = norm_layer(decoder_embed_dim)
-        self.decoder_pred_occ = nn.Linear(decoder_embed_dim, patch_size ** 2 * in_chans, bias=True)
-        self.decoder_pred_free = nn.Linear(decoder_embed_dim, patch_size ** 2 * in_chans, bias=True)
+        if decoder_head == "mlp":
+            self.decoder_pred_occ = nn.Linear(decoder_embed_dim, patch_size ** 2 * in_chans, bias=True)
+            self.decoder_pred_free = nn.Linear(decoder_embed_dim, patch_size ** 2 * in_chans, bias=True)
+        elif patch_size == 8:       # mae_base.py:318-325: the head's 512 input channels are hard-coded in the reference
+            self.decoder_pred_occ = ConvPred(input_size=32, output_size=256, input_chans=512, output_chans=13)
+            self.decoder_pred_free = ConvPred(input_size=32, output_size=256, input_chans=512, output_chans=13)
+        elif patch_size == 16:
+            self.decoder_pred_occ = ConvPred16(input_size=16, output_size=256, input_chans=512, output_chans=13)
+            self.decoder_pred_free = ConvPred16(input_size=16, output_size=256, input_chans=512, output_chans=13)
+        else:
+            raise NotImplementedError("not supported conv head for patch size", patch_size)
 
         self.norm_pix_loss = norm_pix_loss
         self.in_chans = in_chans

@@ -467,3 +467,87 @@ def onehot_rows(idx, k):
     out = torch.empty(idx.numel(), k, dtype=torch.float32, device=idx.device)
     L.check(L.lib().star_onehot_rows(p(idx), p(out), idx.numel(), k, L.stream()))
     return out
+
+
+# ---- joint (latent-level fusion) variant: feature warp, conv-head pieces ---------------------------------------------
+def feat_warp_fuse(feat, theta, num_agent, batch, grid, pos=None):
+    """feat float32 [A*B, G*G, D] -> (fused float32 [A*B, G*G, D] (+ pos), passthrough uint8 [A*B])."""
+    _cuda(feat, theta, num_agent)
+    ab, l, d = feat.shape
+    a = ab // batch
+    assert feat.dtype == torch.float32 and feat.is_contiguous() and l == grid * grid
+    assert theta.dtype == torch.float32 and theta.is_contiguous() and tuple(theta.shape) == (batch, a, a, 8)
+    assert num_agent.dtype in (torch.int32, torch.int64) and num_agent.is_contiguous() and tuple(num_agent.shape) == (batch, a)
+    assert pos is None or (pos.dtype == torch.float32 and pos.is_contiguous() and tuple(pos.shape) == (l, d))
+    out = torch.empty_like(feat)
+    pt = torch.empty(ab, dtype=torch.uint8, device=feat.device)
+    L.check(L.lib().star_feat_warp_fuse(p(feat), p(theta), p(num_agent), int(num_agent.dtype == torch.int64), p(pos), p(out), p(pt), batch, a,
+                                        grid, d, L.stream()))
+    return out, pt
+
+
+def upsample2x(x, n, h, w):
+    """channels-last [n*h*w, C] (bf16 / float32) -> [n*2h*2w, C], bilinear, align_corners=False."""
+    c = x.shape[-1]
+    assert x.is_contiguous() and x.numel() == n * h * w * c
+    y = torch.empty(n * 4 * h * w, c, dtype=x.dtype, device=x.device)
+    L.check(L.lib().star_upsample2x_fwd(p(x), p(y), n, h, w, c, L.dt_of(x), L.stream()))
+    return y
+
+
+def upsample2x_bwd(dy, n, h, w):
+    """float32 gradient [n*2h*2w, C] -> [n*h*w, C]."""
+    c = dy.shape[-1]
+    assert dy.dtype == torch.float32 and dy.is_contiguous() and dy.numel() == n * 4 * h * w * c
+    dx = torch.empty(n * h * w, c, dtype=torch.float32, device=dy.device)
+    L.check(L.lib().star_upsample2x_bwd(p(dy), p(dx), n, h, w, c, L.stream()))
+    return dx
+
+
+def bn_stats(x, eps):
+    """x float32 [R, ld] -> (mean, biased var, rstd) float32 [ld]."""
+    r, ld = x.shape
+    assert x.dtype == torch.float32 and x.is_contiguous()
+    mean, var, rstd = (torch.empty(ld, dtype=torch.float32, device=x.device) for _ in range(3))
+    ws = torch.empty(L.lib().star_bn_ws(ld), dtype=torch.float32, device=x.device)
+    L.check(L.lib().star_bn_stats(p(x), r, ld, float(eps), p(mean), p(var), p(rstd), p(ws), L.stream()))
+    return mean, var, rstd
+
+
+def bn_apply(x, mean, rstd, gamma, beta, relu, dt):
+    r, ld = x.shape
+    y = torch.empty(r, ld, dtype=L.torch_dtype(dt), device=x.device)
+    L.check(L.lib().star_bn_apply(p(x), p(mean), p(rstd), p(gamma), p(beta), int(relu), r, ld, p(y), dt, L.stream()))
+    return y
+
+
+def bn_bwd(x, dy, mean, rstd, gamma, beta, relu, training, dt):
+    """-> (dx in dt [R, ld], dgamma, dbeta float32 [ld])."""
+    r, ld = x.shape
+    assert dy.dtype == torch.float32 and dy.is_contiguous() and tuple(dy.shape) == (r, ld)
+    dx = torch.empty(r, ld, dtype=L.torch_dtype(dt), device=x.device)
+    dgamma = torch.empty(ld, dtype=torch.float32, device=x.device)
+    dbeta = torch.empty(ld, dtype=torch.float32, device=x.device)
+    ws = torch.empty(L.lib().star_bn_ws(ld), dtype=torch.float32, device=x.device)
+    L.check(L.lib().star_bn_bwd(p(x), p(dy), p(mean), p(rstd), p(gamma), p(beta), int(relu), int(training), r, ld, p(dx), dt, p(dgamma), p(dbeta),
+                                p(ws), L.stream()))
+    return dx, dgamma, dbeta
+
+
+def ce_nhwc(lfree, locc, target, c, want_pred=True, want_grad=True):
+    """Two heads' channels-last logits float32 [N*H*W, ld], target float32 [N,C,H,W] (any strides)
+    -> dict(loss [1], ind64 [N,C,H,W], pred [N,2,C,H,W], dfree, docc)."""
+    n, ct, h, w = target.shape
+    ld = lfree.shape[1]
+    assert ct == c and lfree.dtype == torch.float32 and lfree.is_contiguous() and locc.is_contiguous() and tuple(lfree.shape) == (n * h * w, ld) == tuple(locc.shape)
+    dev = lfree.device
+    ind = torch.empty(n, c, h, w, dtype=torch.int64, device=dev)
+    pred = torch.empty(n, 2, c, h, w, dtype=torch.float32, device=dev) if want_pred else None
+    dfree = torch.empty_like(lfree) if want_grad else None
+    docc = torch.empty_like(locc) if want_grad else None
+    nb = L.lib().star_ce_nhwc_blocks(n, h, w)
+    part = torch.empty(nb, dtype=torch.float32, device=dev)
+    loss = torch.empty(1, dtype=torch.float32, device=dev)
+    L.check(L.lib().star_ce_nhwc(p(lfree), p(locc), p(target), L.strides(target), p(ind), p(pred), p(dfree), p(docc), p(part), n, c, h, w, ld, L.stream()))
+    L.check(L.lib().star_ce_finish(p(part), nb, n * c * h * w, p(loss), L.stream()))
+    return dict(loss=loss, ind64=ind, pred=pred, dfree=dfree, docc=docc)

@@ -1,0 +1,138 @@
+"""SURVEY 8(f) rank 1 -- the joint (latent-level fusion) model on the HIP path: AmortizedFusionMMAEViT with the ConvPred /
+ConvPred16 heads (reference star/models/multiagent_mae.py:347-681, star/models/mae_base.py:16-105) against golden vectors
+captured from the reference (fp32 mode: the bar for this row), and the registered full-size factory against the pinned oracle.
+
+The fused latent is a THRESHOLD of summed float features (fusion("sum")), so a feature within rounding distance of 0.5 may land
+on the other side: elements are compared where the reference's pre-threshold sum is not within 1e-3 of 0.5, and everything
+downstream only when no element flipped (true for every fixture in fp32 mode).  bf16 mode runs (smoke) but is not held to a
+bound: bf16 rounding of the features moves ~1 % of the thresholded elements, each by a full unit."""
+from functools import partial
+
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+
+from joint_util import JOINT_CASES, JointCase
+
+pytestmark = pytest.mark.gpu
+
+if torch.cuda.is_available():
+    from oracle import star_oracle as O
+    from star_amd.models import mae_base
+    from star_amd.models import multiagent_mae as mm
+
+DEV = "cuda"
+
+
+def build(c, dtype):
+    m = mm.AmortizedFusionMMAEViT(img_size=c.S, patch_size=c.patch, in_chans=13, embed_dim=32, depth=1, num_heads=2, decoder_embed_dim=64,
+                                  decoder_depth=1, decoder_num_heads=2, mlp_ratio=4, norm_layer=partial(nn.LayerNorm, eps=1e-6),
+                                  decoder_head="conv3", time_stamp=c.T, mask_method=c.mask)
+    head = mae_base.ConvPred if c.patch == 8 else mae_base.ConvPred16
+    m.decoder_pred_occ, m.decoder_pred_free = head(input_chans=64), head(input_chans=64)       # as the fixture generator does
+    m.load_state_dict(c.sd)
+    m = m.to(DEV).set_compute_dtype(dtype)
+    m.train() if c.train else m.eval()
+    m._noise_override = c.noise.to(DEV)
+    m._taps = {}
+    return m
+
+
+def run(m, c):
+    bev = c.bev.to(DEV).permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)          # NHWC memory viewed as NCHW, as CoModule hands over
+    nxt = c.next.to(DEV)
+    teacher = c.teacher.to(DEV).permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)
+    args = (bev, nxt, teacher, torch.from_numpy(c.trans), torch.from_numpy(c.num_agent).to(DEV), c.B)
+    with torch.set_grad_enabled(c.train):
+        return m(*args, mask_ratio=c.mask_ratio)
+
+
+@pytest.mark.parametrize("name", JOINT_CASES)
+def test_joint_fixture_fp32(name):
+    c = JointCase(name)
+    m = build(c, "fp32")
+    loss, result, mask, pred = run(m, c)
+    t = m._taps
+    assert torch.equal(mask.cpu(), torch.from_numpy(c.z["mask"]))
+    torch.testing.assert_close(t["feat"].cpu().reshape(c.tap("feat").shape), c.tap("feat"), rtol=2e-4, atol=2e-4)
+    dpos = m.decoder_pos_embed[0, 1:].cpu()
+    fused = t["fused"].cpu() - dpos                                   # the kernel adds decoder_pos_embed on the way out
+    assert (fused - c.tap("fused")).abs().max() < 1e-3               # no thresholded element flipped (passthrough slots: 2e-4)
+    torch.testing.assert_close(pred.cpu(), c.pred, rtol=5e-4, atol=5e-4)
+    assert abs(loss.item() - c.loss) < 2e-5
+    margin = (c.pred[:, 1] - c.pred[:, 0]).abs().numpy()
+    assert result.dtype == torch.int64 and (result.cpu().numpy() == c.result)[margin > 2e-3].all()
+    if c.train:
+        sd = m.state_dict()
+        for k, v in c.after.items():                                  # BatchNorm running statistics after the training forward
+            torch.testing.assert_close(sd[k].cpu().to(v.dtype), v, rtol=1e-4, atol=1e-5, msg=lambda s, k=k: k + ": " + s)
+        loss.backward()
+        params = dict(m.named_parameters())
+        for k, g in c.grads().items():
+            mine = params[k].grad
+            if g.numel() == 0:
+                assert mine is None, k
+            else:
+                assert mine is not None, k
+                torch.testing.assert_close(mine.cpu(), g, rtol=5e-3, atol=5e-6, msg=lambda s, k=k: k + ": " + s)
+    else:
+        for k, v in c.after.items():                                  # eval mode leaves the buffers alone
+            assert torch.equal(m.state_dict()[k].cpu().to(v.dtype), c.sd[k].to(v.dtype)), k
+
+
+def test_joint_bf16_mode_runs():
+    c = JointCase("joint_T2_rand_train")
+    m = build(c, "bf16")
+    loss, result, mask, pred = run(m, c)
+    loss.backward()
+    assert np.isfinite(loss.item()) and abs(loss.item() - c.loss) < 0.2
+    assert all(torch.isfinite(p.grad).all() for p in m.parameters() if p.grad is not None)
+
+
+def test_joint_full_size_factory_against_oracle():
+    """amortized_joint_patch8_shallow (D = 768, 6 + 6 blocks, Dd = 512, ConvPred 512 -> 256 -> 128 -> 13 at 64/128/256 pixels)
+    on one 3-agent scene with one empty agent slot, fp32 mode against the CPU oracle: features, thresholded latent, logits,
+    loss, decisions, gradients of encoder (through the pass-through slot), decoder and conv-head parameters."""
+    from star_amd.synthetic import make_structured_batch
+    B, A, T = 1, 3, 1
+    torch.manual_seed(0)
+    model = mm.amortized_joint_patch8_shallow(time_stamp=T, mask_method="complement")
+    with torch.no_grad():
+        model.decoder_temp_embed.normal_(std=0.1)
+        model.decoder_embed.bias.add_(0.25)
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    model = model.to(DEV).set_compute_dtype("fp32")
+    model.train()
+    data = make_structured_batch(B, A, T, seed=41, device="cpu", num_agent=[2])
+    bev = data["bev_seq"].squeeze(1).permute(0, 3, 1, 2).contiguous()
+    teacher = data["bev_seq_teacher"].squeeze(1).permute(0, 3, 1, 2).contiguous()
+    noise = torch.rand(A * B, 1024, generator=torch.Generator().manual_seed(5))
+    model._noise_override = noise.to(DEV)
+    model._taps = {}
+    loss, result, mask, pred = model(bev.to(DEV), data["bev_seq_next"].to(DEV), teacher.to(DEV), data["trans_matrices"], data["num_agent"].to(DEV), B)
+    loss.backward()
+    cfg = O.make_cfg(dim=768, depth=6, heads=12, ddim=512, ddepth=6, dheads=16, T=T, mask="complement")
+    osd = O.trainable(sd)
+    taps = {}
+    ol, ores, omask, opred = O.run_joint(osd, cfg, bev, data["bev_seq_next"], teacher, data["trans_matrices"].numpy(), data["num_agent"].numpy(), B,
+                                         noise=noise, training=True, taps=taps)
+    ol.backward()
+    torch.testing.assert_close(model._taps["feat"].cpu().reshape(taps["feat"].shape), taps["feat"].detach(), rtol=3e-4, atol=3e-4)
+    fused = model._taps["fused"].cpu() - model.decoder_pos_embed[0, 1:].cpu()
+    flipped = ((fused - taps["fused"].detach()).abs() > 0.5).float().mean().item()
+    assert flipped < 1e-5, flipped                      # ~1.5 M thresholded elements: at most a handful within rounding of 0.5
+    if flipped == 0.0:
+        torch.testing.assert_close(pred.cpu(), opred.detach(), rtol=2e-3, atol=2e-3)
+        assert abs(loss.item() - ol.item()) < 1e-4
+        margin = (opred[:, 1] - opred[:, 0]).abs().detach().numpy()
+        assert (result.cpu().numpy() == ores.numpy())[margin > 1e-2].all()
+        params = dict(model.named_parameters())
+        for k in ("decoder_pred_occ.conv1.weight", "decoder_pred_occ.bn2.weight", "decoder_pred_free.conv3.weight", "decoder_pred_free.conv3.bias",
+                  "decoder_pred_free.bn3.bias", "decoder_blocks.0.attn.qkv.weight", "decoder_norm.weight", "decoder_embed.weight",
+                  "compressor.0.weight", "blocks.0.mlp.fc1.weight", "patch_embed.proj.weight"):
+            g = osd[k].grad
+            err = float((params[k].grad.cpu() - g).norm())
+            # per tensor, in norm; the absolute term is float32 round-off per element: a conv bias in front of a training-mode
+            # BatchNorm has an analytically ZERO gradient (the mean is subtracted again), both sides hold ~1e-9 noise there
+            assert err <= 2e-3 * float(g.norm()) + 2e-6 * g.numel() ** 0.5, (k, err, float(g.norm()))
