@@ -12,6 +12,10 @@ timeout -s KILL 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_BU
 python3 - "$d" "$root/$out" <<'PY'
 import csv, glob, json, sys, collections
 d, out = sys.argv[1], sys.argv[2]
+workload = None      # the bench line of the profiled run names the workload these counters belong to (bench.py only echoes them for it)
+for line in open("%s/p.log" % d):
+    if line.startswith("{") and '"workload"' in line:
+        workload = json.loads(line)["config"]["workload"]
 fam = [("gemm_nt", ("void gemm_nt_",)), ("gemm_wgrad", ("void gemm_tn_",)), ("attn_fwd", ("void attn_fwd_",)),
        ("attn_bwd", ("void attn_bwd_",)), ("vq_assign", ("void vq_assign_",))]
 agg = collections.defaultdict(lambda: collections.defaultdict(float))
@@ -31,7 +35,7 @@ for name, v in agg.items():
                  "SQ_BUSY_CYCLES": v["SQ_BUSY_CYCLES"], "GRBM_GUI_ACTIVE": v["GRBM_GUI_ACTIVE"],
                  "mfma_util_busy_cycles": v["SQ_VALU_MFMA_BUSY_CYCLES"] / simd_cycles if simd_cycles else None,
                  "mfma_util_insts_x16": v["SQ_INSTS_MFMA"] * 16.0 / simd_cycles if simd_cycles else None}
-json.dump({"note": "rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_BUSY_CYCLES GRBM_GUI_ACTIVE over bench.py --steps 3 --warmup 1; "
+json.dump({"workload": workload, "note": "rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_BUSY_CYCLES GRBM_GUI_ACTIVE over bench.py --steps 3 --warmup 1; "
                    "sums over all launches of a family; denominator = GRBM_GUI_ACTIVE / 8 x 1024 SIMDs (the counter is summed over the 8 XCDs)",
            "families": res}, open(out, "w"), indent=1, sort_keys=True)
 for name, v in res.items():
