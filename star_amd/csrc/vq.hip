@@ -20,6 +20,7 @@
 // K = 8192, E = 32.
 // Deterministic: squared-error partials per workgroup are folded in a fixed order; the histogram is integer.
 #include "common.h"
+#include <type_traits>
 
 typedef __attribute__((ext_vector_type(4))) float vq_f32x4;
 
@@ -69,6 +70,7 @@ __global__ __launch_bounds__(VQ_THREADS) void vq_assign_kernel(const float* __re
     constexpr int NL = (VQ_CH * E4 + VQ_THREADS - 1) / VQ_THREADS;
     constexpr int BUF = VQ_CH * S + VQ_CH;       // floats per buffer: codes, then |e|^2
     float4 stg[NL];
+    bool cbbad = false;                          // a staged code with non-finite |e|^2
     auto fetch = [&](int c0) {
 #pragma unroll
         for (int i = 0; i < NL; ++i) {
@@ -90,48 +92,71 @@ __global__ __launch_bounds__(VQ_THREADS) void vq_assign_kernel(const float* __re
                 *reinterpret_cast<float2*>(d) = make_float2(v.x, v.y);
                 *reinterpret_cast<float2*>(d + 2) = make_float2(v.z, v.w);
                 if (q == 0) buf[VQ_CH * S + c] = sq;
+                cbbad |= !(sq < INFINITY);
             }
         }
     };
-    fetch(0);
-    stash(vq_lds);
-    __syncthreads();
-    int cur = 0;
-    for (int c0 = 0; c0 < K; c0 += VQ_CH) {
-        const bool more = c0 + VQ_CH < K;
-        if (more) fetch(c0 + VQ_CH);
-        const float* buf = vq_lds + cur * BUF;
-        const float* e2 = buf + VQ_CH * S;
-#pragma unroll
-        for (int ct = 0; ct < VQ_CH / 16; ct += 2) {   // two column tiles at a time: two independent accumulator chains
-            vq_f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-            const float* bsrc = buf + (ct * 16 + lr) * S + lg;
-#pragma unroll
-            for (int kk = 0; kk < E4; ++kk) {
-                // B[k = lg][n = lr] = code (ct*16 + lr), element kk*4 + lg
-                acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[kk], bsrc[kk * 4], acc[0], 0, 0, 0);
-                acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[kk], bsrc[16 * S + kk * 4], acc[1], 0, 0, 0);
-            }
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {            // ascending columns per lane: strict < keeps the first minimum
-                const int col = c0 + (ct + h) * 16 + lr;
-                const float ce2 = e2[(ct + h) * 16 + lr];
-                if (col < K) {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        // the reference's evaluation order: (|x|^2 + |e|^2) - 2 * dot, one rounding each
-                        const float d = __fsub_rn(__fadd_rn(rx2[j], ce2), __fmul_rn(2.0f, acc[h][j]));
-                        if (d < bd[j]) {
-                            bd[j] = d;
-                            bi[j] = col;
+    // torch.argmin takes the FIRST NaN distance as the minimum.  A distance can only be NaN when |x|^2 or |e|^2 is not
+    // finite, so the canonicalising compare (NaN -> -inf, two more VALU ops per distance: +8 %) runs only for workgroups that
+    // hold such a row, or -- a second scan -- once a non-finite code has been staged.  Both decisions are workgroup-uniform.
+    auto scan = [&](auto careful) {
+        fetch(0);
+        stash(vq_lds);
+        __syncthreads();
+        int cur = 0;
+        for (int c0 = 0; c0 < K; c0 += VQ_CH) {
+            const bool more = c0 + VQ_CH < K;
+            if (more) fetch(c0 + VQ_CH);
+            const float* buf = vq_lds + cur * BUF;
+            const float* e2 = buf + VQ_CH * S;
+    #pragma unroll
+            for (int ct = 0; ct < VQ_CH / 16; ct += 2) {   // two column tiles at a time: two independent accumulator chains
+                vq_f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+                const float* bsrc = buf + (ct * 16 + lr) * S + lg;
+    #pragma unroll
+                for (int kk = 0; kk < E4; ++kk) {
+                    // B[k = lg][n = lr] = code (ct*16 + lr), element kk*4 + lg
+                    acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[kk], bsrc[kk * 4], acc[0], 0, 0, 0);
+                    acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[kk], bsrc[16 * S + kk * 4], acc[1], 0, 0, 0);
+                }
+    #pragma unroll
+                for (int h = 0; h < 2; ++h) {            // ascending columns per lane: strict < keeps the first minimum
+                    const int col = c0 + (ct + h) * 16 + lr;
+                    const float ce2 = e2[(ct + h) * 16 + lr];
+                    if (col < K) {
+    #pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            // the reference's evaluation order: (|x|^2 + |e|^2) - 2 * dot, one rounding each
+                            float d = __fsub_rn(__fadd_rn(rx2[j], ce2), __fmul_rn(2.0f, acc[h][j]));
+                            if constexpr (decltype(careful)::value) d = (d != d) ? -INFINITY : d;
+                            if (d < bd[j]) {
+                                bd[j] = d;
+                                bi[j] = col;
+                            }
                         }
                     }
                 }
             }
+            if (more) stash(vq_lds + (cur ^ 1) * BUF);
+            __syncthreads();
+            cur ^= 1;
         }
-        if (more) stash(vq_lds + (cur ^ 1) * BUF);
-        __syncthreads();
-        cur ^= 1;
+    };
+    bool rowbad = false;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) rowbad |= !(rx2[j] < INFINITY);
+    if (__syncthreads_or(rowbad)) {
+        scan(std::true_type{});
+    } else {
+        scan(std::false_type{});
+        if (__syncthreads_or(cbbad)) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                bd[j] = INFINITY;
+                bi[j] = 0x7fffffff;
+            }
+            scan(std::true_type{});
+        }
     }
     // minimum over the 16 column residues (lanes of one lg group); ties -> the smaller index
 #pragma unroll
@@ -145,6 +170,7 @@ __global__ __launch_bounds__(VQ_THREADS) void vq_assign_kernel(const float* __re
                 bi[j] = oi;
             }
         }
+        if (bi[j] == 0x7fffffff) bi[j] = 0;          // every distance +inf: argmin's first minimum is code 0
     }
     // outputs: the 16 lanes of a group copy the winning code of each of the group's 4 rows
     float err = 0.f;

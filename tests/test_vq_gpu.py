@@ -91,6 +91,35 @@ def test_quantizer_at_makefile_size_against_oracle():
         torch.testing.assert_close(a1[1].cpu().double(), want * 2 / (m * e), rtol=1e-4, atol=1e-9)
 
 
+def test_quantizer_non_finite_rows_pick_what_argmin_picks():
+    """A diverged run feeds NaN / inf latents: the code index must stay inside the codebook, and follow torch.argmin
+    (reference mae_base.py:221-222): the first NaN distance wins; all distances +inf -> code 0."""
+    g = torch.Generator().manual_seed(1)
+    m, k, e = 200, 130, 32
+    x = torch.relu(torch.randn(m, e, generator=g))
+    cb = torch.randn(k, e, generator=g) * 0.5
+    cb[:7] = cb[:7].abs()                                      # +inf . code: +inf for the first codes, NaN once signs mix
+    x[3] = float("nan")
+    x[17, 5] = float("nan")
+    x[40] = float("inf")
+    x[41, 2] = float("inf")
+    x[90] = 3e19                                               # |x|^2 overflows: every distance is +inf
+    x[199, 31] = float("-inf")
+    d = (x ** 2).sum(1, keepdim=True) + (cb ** 2).sum(1, keepdim=True).t() - 2 * x @ cb.t()
+    want = torch.argmin(d, dim=1)
+    bad = ~torch.isfinite(d).all(1)
+    assert int(bad.sum()) == 6 and want[3] == 0 and want[90] == 0
+    v = ops.vq_assign(x.to(DEV), cb.to(DEV), F32)
+    got = v["idx"].cpu()
+    assert int(got.min()) >= 0 and int(got.max()) < k
+    nanfirst = torch.where(torch.isnan(d).any(1), torch.isnan(d).float().argmax(1), want)
+    assert torch.equal(got[bad], nanfirst[bad]), (got[bad], nanfirst[bad])
+    top2 = torch.topk(d[~bad], 2, dim=1, largest=False).values
+    safe = (top2[:, 1] - top2[:, 0]) > 1e-4
+    assert torch.equal(got[~bad][safe], want[~bad][safe])
+    assert int(v["counts"].sum()) == m
+
+
 def build(c, dtype):
     d = VQ_DIMS
     m = VQSTARViT(img_size=c.S, patch_size=d["patch"], in_chans=d["chans"], embed_dim=d["dim"], depth=d["depth"], num_heads=d["heads"],
