@@ -211,6 +211,13 @@ __device__ __forceinline__ void tr_wait(short4_t (&lo)[4], short4_t (&hi)[4]) {
                  : "+v"(lo[0]), "+v"(lo[1]), "+v"(lo[2]), "+v"(lo[3]), "+v"(hi[0]), "+v"(hi[1]), "+v"(hi[2]), "+v"(hi[3]));
 }
 
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+template <int OFF> __device__ __forceinline__ f32x4_t lds_f4(unsigned addr) {
+    f32x4_t r;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(OFF));
+    return r;
+}
+
 __device__ __forceinline__ short8_t join8(short4_t lo, short4_t hi) { return (short8_t){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]}; }
 
 #define ONES8 ((short8_t){0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80})
@@ -696,8 +703,6 @@ __global__ __launch_bounds__(AT) void attn_bwd_dkv_bf16_kernel(const bf16_t* __r
         if (it + 2 < nt) issue(it + 2, stage >= 1 ? stage - 1 : 2);
         const unsigned char* ql = smem + stage * STAGE;
         const unsigned char* dol = ql + C::TILE;
-        const float* lsl = reinterpret_cast<const float*>(ql + 2 * C::TILE);
-        const float* dll = lsl + 64;
         const unsigned sbase = lds_base + stage * STAGE;
         stage = stage == 2 ? 0 : stage + 1;
 
@@ -711,13 +716,18 @@ __global__ __launch_bounds__(AT) void attn_bwd_dkv_bf16_kernel(const bf16_t* __r
                 tr_issue_half<C::RB>(hb + toff[0][db], hb + toff[1][db], qlo[db], qhi[db]);
                 tr_issue_half<C::RB>(hb + C::TILE + toff[0][db], hb + C::TILE + toff[1][db], dlo[db], dhi[db]);
             }
+            // row constants: asm reads (a compiler-visible read of a region filled by LDS-DMA makes hipcc drain the whole
+            // ring with vmcnt(0) in every iteration); they land in the accumulators' registers, no VALU copy
             f32x16_t s, dp;
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const float4 l4 = *reinterpret_cast<const float4*>(lsl + qblk * 32 + 8 * t + 4 * h2);
-                const float4 d4 = *reinterpret_cast<const float4*>(dll + qblk * 32 + 8 * t + 4 * h2);
-                s[4 * t] = l4.x; s[4 * t + 1] = l4.y; s[4 * t + 2] = l4.z; s[4 * t + 3] = l4.w;
-                dp[4 * t] = d4.x; dp[4 * t + 1] = d4.y; dp[4 * t + 2] = d4.z; dp[4 * t + 3] = d4.w;
+            {
+                const unsigned ca = sbase + 2 * C::TILE + (qblk * 32 + 4 * h2) * 4;
+                const f32x4_t l0 = lds_f4<0>(ca), l1 = lds_f4<32>(ca), l2 = lds_f4<64>(ca), l3 = lds_f4<96>(ca);
+                const f32x4_t d0 = lds_f4<256>(ca), d1 = lds_f4<288>(ca), d2 = lds_f4<320>(ca), d3 = lds_f4<352>(ca);
+                s = __builtin_shufflevector(__builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7),
+                                            __builtin_shufflevector(l2, l3, 0, 1, 2, 3, 4, 5, 6, 7), 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15);
+                dp = __builtin_shufflevector(__builtin_shufflevector(d0, d1, 0, 1, 2, 3, 4, 5, 6, 7),
+                                             __builtin_shufflevector(d2, d3, 0, 1, 2, 3, 4, 5, 6, 7), 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15);
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(s), "+v"(dp));
             }
 #pragma unroll
             for (int ks = 0; ks < C::KS; ++ks) {

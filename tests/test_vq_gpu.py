@@ -118,6 +118,14 @@ def test_quantizer_non_finite_rows_pick_what_argmin_picks():
     safe = (top2[:, 1] - top2[:, 0]) > 1e-4
     assert torch.equal(got[~bad][safe], want[~bad][safe])
     assert int(v["counts"].sum()) == m
+    # a non-finite CODE (found while staging: the workgroup scans a second time): its distance is NaN for every row
+    x2 = torch.relu(torch.randn(m, e, generator=g))
+    cb2 = cb.clone()
+    cb2[50, 3] = float("inf")
+    d2 = (x2 ** 2).sum(1, keepdim=True) + (cb2 ** 2).sum(1, keepdim=True).t() - 2 * x2 @ cb2.t()
+    assert torch.isnan(d2[:, 50]).all() and (torch.argmin(d2, dim=1) == 50).all()
+    v2 = ops.vq_assign(x2.to(DEV), cb2.to(DEV), F32)
+    assert (v2["idx"].cpu() == 50).all()
 
 
 def build(c, dtype):
