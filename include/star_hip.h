@@ -146,6 +146,13 @@ int star_attn_fwd(const void* qkv, void* out, float* lse, int NB, int L, int H, 
 /* dqkv [NB, L, 3, H, hd] from dout [NB, L, H*hd]; delta float32 [2, NB, H, L] is workspace. */
 int star_attn_bwd(const void* qkv, const void* out, const void* dout, const float* lse, float* delta,
                   void* dqkv, int NB, int L, int H, int hd, int dt, void* stream);
+/* The same gradient (the autograd backward of timm Attention.forward, mae_base.py:279-281) with a workspace the library
+ * sizes: ws float32 of star_attn_bwd_ws_bytes(...) bytes.  bf16 with hd <= 32 runs ONE kernel that sweeps the scores once
+ * for dQ, dK and dV (dK / dV bit-identical to star_attn_bwd; dQ sums its keys in another, fixed order); every other
+ * case runs star_attn_bwd's kernels.  ws_bytes smaller than required -> error. */
+int64_t star_attn_bwd_ws_bytes(int NB, int L, int H, int hd, int dt);
+int star_attn_bwd_ws(const void* qkv, const void* out, const void* dout, const float* lse, float* ws, int64_t ws_bytes,
+                     void* dqkv, int NB, int L, int H, int hd, int dt, void* stream);
 
 /* ---- K1: voxel -> patch gather ------------------------------------------------------------------------
  * Replaces the im2col half of Conv2d(13, D, k=p, s=p) + flatten(2).transpose(1,2) (timm PatchEmbed;

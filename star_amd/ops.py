@@ -4,6 +4,8 @@ import ctypes as C
 import math
 
 import numpy as np
+import os
+
 import torch
 
 from . import _lib as L
@@ -221,10 +223,24 @@ def attn_fwd(qkv, nb, l, h, hd):
     return out, lse
 
 
-def attn_bwd(qkv, out, dout, lse, nb, l, h, hd):
+_ATTN_FUSED = os.environ.get("STAR_AMD_ATTN_FUSED", "0") == "1"
+
+
+def attn_bwd(qkv, out, dout, lse, nb, l, h, hd, fused=None):
+    """dqkv [NB*L, 3*H*hd].  fused=True: star_attn_bwd_ws (bf16, hd <= 32: one sweep over the scores for dQ, dK, dV);
+    fused=False: star_attn_bwd (a dQ kernel and a dK/dV kernel, each recomputing the scores).  Default: the two-kernel
+    path (faster inside the training step as measured), STAR_AMD_ATTN_FUSED=1 switches."""
+    if fused is None:
+        fused = _ATTN_FUSED
     dt = L.dt_of(qkv)
     assert qkv.is_contiguous() and out.is_contiguous() and dout.is_contiguous() and dout.dtype == qkv.dtype
     dqkv = torch.empty_like(qkv)
+    if fused:
+        nbytes = L.lib().star_attn_bwd_ws_bytes(nb, l, h, hd, dt)
+        ws = torch.empty(nbytes // 4, dtype=torch.float32, device=qkv.device)   # delta | scaled lse | fp32 dQ partial (L > 512)
+        with _timed("attn_bwd", 10.0 * nb * h * l * l * hd):
+            L.check(L.lib().star_attn_bwd_ws(p(qkv), p(out), p(dout), p(lse), p(ws), nbytes, p(dqkv), nb, l, h, hd, dt, L.stream()))
+        return dqkv
     delta = torch.empty(2, nb, h, l, dtype=torch.float32, device=qkv.device)   # workspace: delta | scaled lse
     with _timed("attn_bwd", 10.0 * nb * h * l * l * hd):
         L.check(L.lib().star_attn_bwd(p(qkv), p(out), p(dout), p(lse), p(delta), p(dqkv), nb, l, h, hd, dt, L.stream()))

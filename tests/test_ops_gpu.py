@@ -380,6 +380,48 @@ def test_attention_fwd_bwd(dt, NB, L, H, hd):
     torch.testing.assert_close(dqkv.double(), dref, **tolb)
 
 
+@pytest.mark.parametrize("NB,L,H,hd", [(1, 1, 1, 16), (2, 16, 2, 16), (3, 64, 3, 32), (2, 342, 2, 16), (1, 300, 3, 32), (1, 512, 2, 32),
+                                       (1, 513, 1, 16), (2, 700, 2, 32), (2, 1024, 3, 32), (2, 1024, 4, 16), (1, 1500, 1, 32),
+                                       (1, 1100, 2, 16)])
+def test_attention_bwd_fused_against_two_kernel_path(NB, L, H, hd):
+    """star_attn_bwd_ws (one sweep) against star_attn_bwd (two kernels): dK and dV accumulate the same products in the same
+    order -> bit for bit; dQ sums its keys in another order (64-key partials per wave, waves in order, 512-key passes) ->
+    the bf16 tolerance of the float64 reference, and run-to-run bit-stable."""
+    g = torch.Generator().manual_seed(7 * NB + L + H + hd)
+    qkv = _rand_lp((NB * L, 3 * H * hd), g, 0, 1.5)
+    dout = _rand_lp((NB * L, H * hd), g, 0)
+    out, lse = ops.attn_fwd(qkv, NB, L, H, hd)
+    two = ops.attn_bwd(qkv, out, dout, lse, NB, L, H, hd, fused=False).reshape(NB * L, 3, H * hd)
+    one = ops.attn_bwd(qkv, out, dout, lse, NB, L, H, hd, fused=True).reshape(NB * L, 3, H * hd)
+    assert torch.equal(one[:, 1], two[:, 1]) and torch.equal(one[:, 2], two[:, 2])
+    _, dref = _attn_ref(qkv, NB, L, H, hd, dout)
+    dref = dref.reshape(NB * L, 3, H * hd)
+    torch.testing.assert_close(one[:, 0].double(), dref[:, 0], rtol=3e-2, atol=4e-2)
+    nrm = dref[:, 0].norm().clamp_min(1e-30)                    # L = 1: dQ is exactly zero
+    e1 = (one[:, 0].double() - dref[:, 0]).norm() / nrm
+    e2 = (two[:, 0].double() - dref[:, 0]).norm() / nrm
+    assert e1 < 1.25 * e2 + 1e-4, (float(e1), float(e2))
+    again = ops.attn_bwd(qkv, out, dout, lse, NB, L, H, hd, fused=True).reshape(NB * L, 3, H * hd)
+    assert torch.equal(again, one)
+
+
+def test_attention_bwd_ws_checks_its_workspace():
+    NB, L, H, hd = 1, 1024, 2, 32
+    from star_amd import _lib as L_
+    lib = L_.lib()
+    assert lib.star_attn_bwd_ws_bytes(NB, L, H, hd, 0) == (2 * NB * H * L + NB * H * L * hd) * 4
+    assert lib.star_attn_bwd_ws_bytes(NB, 512, H, hd, 0) == 2 * NB * H * 512 * 4
+    assert lib.star_attn_bwd_ws_bytes(NB, L, H, 64, 0) == 2 * NB * H * L * 4      # hd 64: the two-kernel path
+    assert lib.star_attn_bwd_ws_bytes(NB, L, H, hd, 1) == 2 * NB * H * L * 4      # fp32 mode: the vector-ALU kernels
+    qkv = torch.zeros(NB * L, 3 * H * hd, device=DEV, dtype=torch.bfloat16)
+    o = torch.zeros(NB * L, H * hd, device=DEV, dtype=torch.bfloat16)
+    lse = torch.zeros(NB, H, L, device=DEV)
+    ws = torch.empty(2 * NB * H * L, device=DEV)
+    rc = lib.star_attn_bwd_ws(qkv.data_ptr(), o.data_ptr(), o.data_ptr(), lse.data_ptr(), ws.data_ptr(), ws.numel() * 4,
+                              torch.empty_like(qkv).data_ptr(), NB, L, H, hd, 0, None)
+    assert rc != 0 and "workspace" in lib.star_last_error().decode()
+
+
 def test_attention_one_hot_rows_catch_layout_errors():
     """Integer data: V rows one-hot, q.k chosen so that every query attends (almost) only to one key."""
     NB, L, H, hd = 1, 64, 1, 32
