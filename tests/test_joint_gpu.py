@@ -136,3 +136,36 @@ def test_joint_full_size_factory_against_oracle():
             # per tensor, in norm; the absolute term is float32 round-off per element: a conv bias in front of a training-mode
             # BatchNorm has an analytically ZERO gradient (the mean is subtracted again), both sides hold ~1e-9 noise there
             assert err <= 2e-3 * float(g.norm()) + 2e-6 * g.numel() ** 0.5, (k, err, float(g.norm()))
+
+
+def test_joint_model_trains_through_comodule():
+    """The reference's training call sequence (completion/train_completion.py:124-136,278) with the joint model: torch AdamW over
+    timm's decay groups, CoModule(..., "joint_mae").step_mae_completion(trainable=True).  fp32 mode; the loss on a fixed batch
+    must fall, the BatchNorm running statistics move, every parameter stays finite, and an evaluation call leaves the buffers
+    alone."""
+    from star_amd.optim import add_weight_decay
+    from star_amd.synthetic import make_structured_batch
+    from star_amd.utils.CoModule import CoModule
+    torch.manual_seed(3)
+    c = JointCase("joint_T1_comp_train")
+    m = build(c, "fp32")
+    m._noise_override = None
+    m._taps = None
+    m.train()
+    opt = torch.optim.AdamW(add_weight_decay(m, 0.05), lr=2e-3, betas=(0.9, 0.95))
+    co = CoModule(m, opt, "joint_mae")
+    data = make_structured_batch(2, c.A, c.T, seed=9, device=DEV, size=c.S)
+    rm0 = m.decoder_pred_occ.bn1.running_mean.clone()
+    losses = []
+    for _ in range(12):
+        loss, result, ind = co.step_mae_completion(data, 2, 0.0, trainable=True)
+        losses.append(loss)
+    assert all(np.isfinite(losses)) and losses[-1] < 0.8 * losses[0], losses
+    assert result.shape == (2 * c.A, 13, c.S, c.S) and result.dtype == torch.int64
+    assert not torch.equal(m.decoder_pred_occ.bn1.running_mean, rm0)
+    assert all(torch.isfinite(p).all() for p in m.parameters())
+    m.eval()
+    rm1 = m.decoder_pred_occ.bn1.running_mean.clone()
+    with torch.no_grad():
+        l2, r2, _, _ = m(*co._unpack(data), 2, mask_ratio=0.0)
+    assert torch.equal(m.decoder_pred_occ.bn1.running_mean, rm1) and np.isfinite(l2.item())
