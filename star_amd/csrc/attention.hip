@@ -542,6 +542,10 @@ __global__ __launch_bounds__(AT) void attn_bwd_dq_bf16_kernel(const bf16_t* __re
         pin(dof[ks]);
     }
     asm volatile("" : "+v"(ls), "+v"(ndl));
+    f32x16_t ndl16;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) ndl16[e] = ndl;
+    asm volatile("" : "+v"(ndl16));   // materialised once: not re-splatted per block
 
     __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(qb), 0, (unsigned)((L * rs - h * HD) * 2), 0x00020000);
     unsigned src[NI];
@@ -594,16 +598,18 @@ __global__ __launch_bounds__(AT) void attn_bwd_dq_bf16_kernel(const bf16_t* __re
         for (int db = 0; db < C::DB; ++db) tr_issue<C::RB>(sbase + toff[0][db], sbase + toff[1][db], klo[db], khi[db]);
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
-            f32x16_t s, dp;
+            // dP starts from the lane's -delta (a 16-register splat kept for the whole kernel, handed to the first MFMA as its
+            // C operand): dS = p (dP - delta) costs no add per score
+            f32x16_t s, dp = ndl16;
 #pragma unroll
-            for (int e = 0; e < 16; ++e) s[e] = dp[e] = 0.f;
+            for (int e = 0; e < 16; ++e) s[e] = 0.f;
 #pragma unroll
             for (int ks = 0; ks < C::KS; ++ks) {
                 s = mfma32(*reinterpret_cast<const short8_t*>(kl + koff[ks] + kb * 32 * C::RB), qf[ks], s);
                 dp = mfma32(*reinterpret_cast<const short8_t*>(vl + koff[ks] + kb * 32 * C::RB), dof[ks], dp);
             }
 #pragma unroll
-            for (int e = 0; e < 16; ++e) s[e] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[e], c, -ls)) * (dp[e] + ndl);
+            for (int e = 0; e < 16; ++e) s[e] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[e], c, -ls)) * dp[e];
             if (kb == 0) {
                 tr_wait(klo[0], khi[0]);
                 if constexpr (C::DB == 2) tr_wait(klo[1], khi[1]);
