@@ -232,7 +232,7 @@ __global__ __launch_bounds__(GT) void gemm_nt_kernel(const StarGemm g) {
                     st4(pre + (size_t)d * N + n0, dv);
                 }
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+                for (int e = 0; e < 4; ++e) v[e] = v[e] < 0.f ? 0.f : v[e];   // NaN stays NaN, as torch.relu (a max would drop it)
             } else if (g.act == STAR_ACT_DGELU) {
                 float t[4];
                 ld4(aux + (size_t)m * N + n0, t);
@@ -611,7 +611,7 @@ void gemm_nt_fast_kernel(const StarGemm g) {
                     st_runs_lp(pre + (size_t)d * N, dv);
                 }
 #pragma unroll
-                for (int e = 0; e < 16; ++e) v[e] = fmaxf(v[e], 0.f);
+                for (int e = 0; e < 16; ++e) v[e] = v[e] < 0.f ? 0.f : v[e];   // NaN stays NaN, as torch.relu (a max would drop it)
             } else if (use_aux) {
                 if (has_res) {   // both a residual and an activation gradient: the aux row was not prefetched
                     float t[16];

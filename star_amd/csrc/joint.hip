@@ -277,7 +277,7 @@ __global__ __launch_bounds__(JT) void bn_apply_kernel(const float* __restrict__ 
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             v[k] = (v[k] - m[k]) * rs[k] * g[k] + b[k];
-            if (relu) v[k] = v[k] > 0.f ? v[k] : 0.f;
+            if (relu) v[k] = v[k] < 0.f ? 0.f : v[k];   // NaN stays NaN, as torch.relu
         }
         st4(y + (id / cv) * ld + c4, v);
     }

@@ -50,6 +50,7 @@ class SceneParallel:
         self.deferred = []
         self.active = self.world > 1 or (force and dist.is_initialized())
         self._host = None           # gloo + device tensors: pinned staging image of the flat gradient buffer
+        self._flag_stream = self._flag_event = None     # RCCL: side stream of the agreed non-finite-loss flag
         model._on_grads_ready = self._ready if self.active else None
 
     # ---- start-up -------------------------------------------------------------------------------------------------
@@ -119,14 +120,25 @@ class SceneParallel:
                 view.copy_(host, non_blocking=True)             # stream-ordered in front of the optimizer kernel
         self.pending = []
 
-    def nonfinite_flag(self, loss):
-        """Device float32 [1], in stream order: 1 if the loss of ANY rank is not finite (RCCL; the host does not block).
-        None when the transport cannot do that without blocking (gloo): use any_rank() on the host value instead."""
+    def nonfinite_flag_to(self, loss, host_slot):
+        """Queue "is the loss of ANY rank not finite" (a one-word MAX all-reduce over RCCL) and its copy into the pinned
+        `host_slot` on a side stream; returns the event that marks the copy, or None when the transport cannot do that without
+        blocking the host (gloo: use any_rank() on the host value instead).  The COMPUTE stream is not made to wait for the
+        collective: the backward queued behind this call starts at once, and the flag's latency (and the ranks' skew at the end
+        of the forward) stays off the step's critical path.  RCCL sees the flag before the step's gradient buckets on every rank."""
         if not (self.active and self.native_avg):
             return None
+        if self._flag_stream is None:
+            self._flag_stream = torch.cuda.Stream()
+            self._flag_event = torch.cuda.Event()
         flag = (~torch.isfinite(loss.detach())).to(torch.float32).reshape(1)
-        dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=self.group)
-        return flag
+        self._flag_stream.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(self._flag_stream):
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=self.group)
+            host_slot.copy_(flag, non_blocking=True)
+            self._flag_event.record(self._flag_stream)
+        flag.record_stream(self._flag_stream)
+        return self._flag_event
 
     def any_rank(self, bad):
         """Host-side agreement (gloo rehearsal / CPU tests): True on every rank if `bad` is True on any."""

@@ -56,20 +56,22 @@ class CoModule(object):
             # bucketed gradient all-reduce) is enqueued; the host waits for the copy only, so the finite check still precedes
             # the update while the GPU never idles on a round trip -- the optimizer launch is queued behind the backward.
             # Multi-rank: the ranks must take the stop/continue decision TOGETHER (a rank that exits alone leaves the others
-            # blocked in the gradient all-reduce): a one-word MAX all-reduce of "my loss is not finite" rides between forward
-            # and backward on RCCL's stream and comes back in the same pinned copy as the loss.
+            # blocked in the gradient all-reduce): a one-word MAX all-reduce of "my loss is not finite" is queued on RCCL's stream
+            # ahead of the gradient buckets and lands in the pinned pair beside the loss through a side stream.
             if self._loss_host is None:
                 self._loss_host = torch.zeros(2, dtype=torch.float32).pin_memory()
                 self._loss_event = torch.cuda.Event()
-            flag = self.parallel.nonfinite_flag(loss) if self.parallel is not None else None
+            self._loss_host[1] = 0.0
             self._loss_host[0:1].copy_(loss.detach().reshape(1), non_blocking=True)
-            if flag is not None:
-                self._loss_host[1:2].copy_(flag, non_blocking=True)
             self._loss_event.record()
+            flag_event = self.parallel.nonfinite_flag_to(loss, self._loss_host[1:2]) if self.parallel is not None else None
             loss.backward()
             self._loss_event.synchronize()
+            if flag_event is not None:
+                flag_event.synchronize()
             loss_value = float(self._loss_host[0])
-            bad = not math.isfinite(loss_value) or (flag is not None and float(self._loss_host[1]) > 0)
+            bad = not math.isfinite(loss_value) or float(self._loss_host[1]) > 0
+            flag = flag_event
             if self.parallel is not None and flag is None:
                 bad = self.parallel.any_rank(bad)                  # gloo rehearsal: agreed on the host
         else:

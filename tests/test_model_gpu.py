@@ -189,6 +189,16 @@ def test_scene_parallel_rccl_call_path_single_rank():
                 loss, _, _ = cm.step_mae_completion(data, 2, 0.75, trainable=True)
             outs.append((loss, opt.flat_p.detach().clone()))
             assert par is None or len(par.pending) == 0
+            if par is not None:
+                # the agreed stop decision: the flag travels over RCCL on its own stream, beside the backward
+                bad = dict(data)
+                bad["bev_seq"] = torch.full_like(data["bev_seq"], float("nan"))     # every kept token carries it into the loss
+                before = opt.flat_p.detach().clone()
+                with pytest.raises(SystemExit):
+                    cm.step_mae_completion(bad, 2, 0.75, trainable=True)
+                torch.cuda.synchronize()
+                assert torch.equal(opt.flat_p, before)          # no update was applied
+                par.finish()                                     # drain the buckets of the abandoned step
         assert outs[0][0] == outs[1][0] and torch.equal(outs[0][1], outs[1][1])
     finally:
         dist.destroy_process_group()

@@ -348,6 +348,24 @@ def test_iou_confusion_vs_oracle():
         assert np.array_equal(np.array([O.occupancy_iou(c) for c in conf]), z["iou_every_batch"][b])
 
 
+@pytest.mark.parametrize("dt", [0, 1])
+@pytest.mark.parametrize("m,n,k", [(256, 128, 384), (70, 32, 96)])        # the fast kernel's shape and a generic-kernel shape
+def test_relu_epilogue_keeps_nan_like_torch_relu(dt, m, n, k):
+    """torch.relu(NaN) is NaN: the reference's non-finite-loss stop (CoModule.py:116-122) depends on a NaN reaching the loss through
+    the compressor's ReLU.  (A max-based ReLU returns 0 for NaN and would train on.)"""
+    g = torch.Generator().manual_seed(3)
+    a = _rand_lp((m, k), g, dt)
+    w = _rand_lp((n, k), g, dt)
+    a[5, 7] = float("nan")
+    lp, f32, _ = ops.gemm(a, w, act=ACT_RELU, want_f32=True)
+    want = torch.relu(a.double() @ w.double().t())
+    assert torch.isnan(want[5]).all() and torch.isnan(f32[5]).all() and torch.isnan(lp[5]).all()
+    keep = torch.ones(m, dtype=torch.bool, device=DEV)
+    keep[5] = False
+    assert not torch.isnan(f32[keep]).any()
+    torch.testing.assert_close(f32[keep].double(), want[keep], rtol=2e-2 if dt == 0 else 1e-4, atol=2e-2 if dt == 0 else 1e-4)
+
+
 # ------------------------------------------------------------------------------------------------
 def _attn_ref(qkv, NB, L, H, hd, dout=None):
     x = qkv.double().reshape(NB, L, 3, H, hd).permute(2, 0, 3, 1, 4).detach().requires_grad_(True)
