@@ -153,6 +153,20 @@ def test_cpu_input_is_rejected_loudly():
         m.inference(c.bev, c.next, c.teacher, torch.from_numpy(c.trans), torch.from_numpy(c.num_agent), c.B)
 
 
+def test_shape_errors_follow_the_reference_conventions():
+    """AssertionError where the reference asserts: rows not a multiple of batch_size (multiagent_mae.py:878), a window that does
+    not hold time_stamp frames (:959), a frame that is not img_size x img_size x 13 (mae_base.py:383)."""
+    c = Case("tiny_T3_comp_train")
+    m = build(c, "fp32")
+    trans, na = torch.from_numpy(c.trans), torch.from_numpy(c.num_agent)
+    with pytest.raises(AssertionError):
+        m(c.bev.to(DEV), c.next.to(DEV), c.teacher.to(DEV), trans, na.to(DEV), c.B + 1 if (c.A * c.B) % (c.B + 1) else c.B + 2)
+    with pytest.raises(AssertionError):
+        m(c.bev.to(DEV), c.next[:, :1].to(DEV), c.teacher.to(DEV), trans, na.to(DEV), c.B)
+    with pytest.raises(AssertionError):
+        m(c.bev[:, :, :-8].to(DEV), c.next.to(DEV), c.teacher.to(DEV), trans, na.to(DEV), c.B)
+
+
 def test_scene_parallel_rccl_call_path_single_rank():
     """The bucketed, backward-overlapped gradient all-reduce on the real RCCL backend with ONE rank (all a single-GPU box
     can host): AVG over one rank is the identity, so parameters after two fused steps must equal the run without it,
