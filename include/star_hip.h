@@ -137,6 +137,17 @@ int64_t star_gemm_wgrad_ws(int M, int N, int K);
 int star_gemm_wgrad(const void* dY, const void* X, const int32_t* x_rows, float* dW, float* db, float* ws,
                     int M, int N, int K, int dt, void* stream);
 
+/* ---- K3': the block's MLP forward as one kernel ---------------------------------------------------------
+ * Replaces timm 0.3.2 Mlp.forward plus the block's second residual add (Block.forward: x = x + mlp(norm2(x)); ctor
+ * mae_base.py:279-281,308-310): xout[M, D] (float32) = xres + fc2(gelu(fc1(h))) with h [M, D], w1 [HID, D], w2 [D, HID] in bf16
+ * (the Linear weights as they lie in memory), b1 [HID], b2 [D] float32.  xout may be xres.  Training: v_out / g_out [M, HID]
+ * bf16 receive gelu(u) and gelu'(u) (what the backward reads); inference: both NULL.  The hidden activations stay on chip.
+ * star_mlp_fwd_supported(D, HID, dt) != 0 tells whether a kernel exists for the shape (bf16, D = 256 or 384, HID % 32 == 0,
+ * HID <= 2048); other shapes -> error (callers use two star_gemm launches instead). */
+int star_mlp_fwd_supported(int D, int HID, int dt);
+int star_mlp_fwd(const void* h, const void* w1, const float* b1, const void* w2, const float* b2, const float* xres,
+                 float* xout, void* v_out, void* g_out, int M, int D, int HID, int dt, void* stream);
+
 /* ---- K4: attention -----------------------------------------------------------------------------------
  * Replaces timm Attention.forward between qkv and proj: softmax(q k^T hd^-0.5) v, no mask, no
  * dropout.  qkv [NB, L, 3, H, hd] in `dt` (the qkv Linear output as it lies in memory), out

@@ -158,10 +158,13 @@ def _block_fwd(x, P, W, pre, heads, nb, l, dt, eps, save, train):
                            want_f32=True, out_f32=None if train else x)
     h2, mean2, rstd2 = ops.layernorm_fwd(x_mid, P[pre + "norm2.weight"], P[pre + "norm2.bias"], eps, dt, want_stats=train)
     # u is not the pre-activation but gelu'(pre-activation): all the backward needs of it (flag PRE_IS_GRAD)
-    v, _, u = ops.gemm(h2, _lin(P, W, pre + "mlp.fc1", dt), bias=P[pre + "mlp.fc1.bias"], act=ACT_GELU, want_pre=train,
-                       flags=GEMM_PRE_IS_GRAD)
-    _, x_out, _ = ops.gemm(v, _lin(P, W, pre + "mlp.fc2", dt), bias=P[pre + "mlp.fc2.bias"], res=x_mid, want_lp=False,
-                           want_f32=True, out_f32=None if train else x_mid)
+    w1, w2 = _lin(P, W, pre + "mlp.fc1", dt), _lin(P, W, pre + "mlp.fc2", dt)
+    if _MLP_FUSED and ops.mlp_supported(d, w1.shape[0], dt):
+        x_out, v, u = ops.mlp_fwd(h2, w1, P[pre + "mlp.fc1.bias"], w2, P[pre + "mlp.fc2.bias"], x_mid, train, out=None if train else x_mid)
+    else:
+        v, _, u = ops.gemm(h2, w1, bias=P[pre + "mlp.fc1.bias"], act=ACT_GELU, want_pre=train, flags=GEMM_PRE_IS_GRAD)
+        _, x_out, _ = ops.gemm(v, w2, bias=P[pre + "mlp.fc2.bias"], res=x_mid, want_lp=False, want_f32=True,
+                               out_f32=None if train else x_mid)
     if train:
         save.append(dict(pre=pre, x=x, mean1=mean1, rstd1=rstd1, h1=h1, qkv=qkv, a=a, lse=lse, x_mid=x_mid, mean2=mean2,
                          rstd2=rstd2, h2=h2, u=u, v=v, heads=heads, nb=nb, l=l))
@@ -232,6 +235,7 @@ class _SideStream:
             self.used = False
 
 
+_MLP_FUSED = os.environ.get("STAR_AMD_MLP_FUSED", "0") == "1"       # the block MLP forward as one kernel (star_mlp_fwd): measured slower, opt-in
 _SKIP_WGRAD = os.environ.get("STAR_AMD_SKIP_WGRAD", "0") == "1"   # measurement only (wrong gradients): the backward chain without its weight-gradient GEMMs
 
 

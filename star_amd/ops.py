@@ -210,6 +210,29 @@ def gemm_wgrad(dy, x, x_rows=None, want_bias=True, want_weight=True, dw=None, db
     return dw, db
 
 
+def mlp_supported(d, hid, dt):
+    return bool(L.lib().star_mlp_fwd_supported(d, hid, dt))
+
+
+def mlp_fwd(h, w1, b1, w2, b2, xres, train, out=None):
+    """x_out = xres + fc2(gelu(fc1(h))) in one kernel (star_mlp_fwd).  h [M, D], w1 [HID, D], w2 [D, HID] bf16; xres float32 [M, D].
+    Returns (x_out float32, v, g): v = gelu(u), g = gelu'(u) ([M, HID] bf16) when `train`, else None.  `out` may be xres."""
+    _cuda(h, w1, w2, xres)
+    m, d = h.shape
+    hid = w1.shape[0]
+    dt = L.dt_of(h)
+    assert h.is_contiguous() and w1.is_contiguous() and w2.is_contiguous() and xres.is_contiguous()
+    assert w1.shape == (hid, d) and w2.shape == (d, hid) and xres.shape == (m, d) and xres.dtype == torch.float32
+    assert w1.dtype == h.dtype and w2.dtype == h.dtype and b1.dtype == torch.float32 and b2.dtype == torch.float32
+    if out is None:
+        out = torch.empty_like(xres)
+    v = torch.empty(m, hid, dtype=h.dtype, device=h.device) if train else None
+    g = torch.empty(m, hid, dtype=h.dtype, device=h.device) if train else None
+    with _timed("mlp_fwd", 4.0 * m * d * hid, float(m * d * (2 + 4 + 4) + (2 * m * hid * 2 if train else 0))):
+        L.check(L.lib().star_mlp_fwd(p(h), p(w1), p(b1), p(w2), p(b2), p(xres), p(out), p(v), p(g), m, d, hid, dt, L.stream()))
+    return out, v, g
+
+
 # ---------------------------------------------------------------------------------------------------
 def attn_fwd(qkv, nb, l, h, hd):
     """qkv [NB*L, 3*H*hd] -> (out [NB*L, H*hd], lse float32 [NB, H, L])."""

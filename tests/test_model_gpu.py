@@ -218,6 +218,34 @@ def test_scene_parallel_rccl_call_path_single_rank():
         dist.destroy_process_group()
 
 
+def test_full_size_model_with_the_one_kernel_mlp_matches_the_two_gemm_path(monkeypatch):
+    """STAR_AMD_MLP_FUSED=1 (star_mlp_fwd in every block) against the default path on the benchmarked model, bf16, training:
+    same loss to 1e-4, identical decisions but for near-ties, gradients within the bf16 noise of the two paths."""
+    from star_amd import engine
+    from star_amd.models import multiagent_mae as mm
+    from star_amd.synthetic import make_batch
+
+    B, A, T = 1, 3, 1
+    data = make_batch(B, A, T, seed=13, occupancy=0.05, device=DEV)
+    noise = torch.rand(A * B, 1024, generator=torch.Generator().manual_seed(5)).to(DEV)
+    outs = []
+    for fused in (False, True):
+        monkeypatch.setattr(engine, "_MLP_FUSED", fused)
+        torch.manual_seed(0)
+        model = mm.amortized_ind_patch8_light(time_stamp=T, mask_method="complement").to(DEV).set_compute_dtype("bf16")
+        model.train()
+        model._noise_override = noise
+        bev = data["bev_seq"].squeeze(1).permute(0, 3, 1, 2)
+        loss, result, latent, ind = model(bev, data["bev_seq_next"], bev, data["trans_matrices"], data["num_agent"], B)
+        loss.backward()
+        g = torch.cat([p.grad.reshape(-1) for p in model.parameters() if p.grad is not None])
+        outs.append((loss.item(), ind.clone(), g.clone()))
+    assert abs(outs[0][0] - outs[1][0]) < 1e-4 * max(1.0, abs(outs[0][0]))
+    assert (outs[0][1] != outs[1][1]).float().mean().item() < 2e-3
+    rel = (outs[0][2] - outs[1][2]).norm() / outs[0][2].norm()
+    assert rel < 2e-2, float(rel)
+
+
 def test_full_size_light_model_against_oracle():
     """The benchmarked model (amortized_ind_patch8_light, 256 x 256 x 13, L = 1024 tokens, hd 32 / 16) on one 3-agent scene
     with T = 2: HIP fp32 mode against the CPU oracle on the same weights, inputs and mask noise -- the size at which

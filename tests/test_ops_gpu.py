@@ -348,6 +348,55 @@ def test_iou_confusion_vs_oracle():
         assert np.array_equal(np.array([O.occupancy_iou(c) for c in conf]), z["iou_every_batch"][b])
 
 
+@pytest.mark.parametrize("train", [True, False])
+@pytest.mark.parametrize("M,D,HID", [(128, 384, 1536), (300, 256, 1024), (1000, 384, 96), (77, 256, 64), (1, 384, 32), (4133, 256, 1024)])
+def test_mlp_fwd_one_kernel_against_two_gemms_and_float64(M, D, HID, train):
+    """star_mlp_fwd (fc1 -> GELU -> fc2 + residual with the hidden activations on chip) against the two star_gemm launches it
+    replaces and against float64: the same bf16 operands and the same bf16 rounding of gelu(u) between the GEMMs, so the
+    two paths differ only in fp32 summation order (a rare 1-ulp flip of a bf16 hidden value); gelu / gelu' outputs as stored
+    for the backward; ragged M; in-place residual in inference."""
+    g = torch.Generator().manual_seed(M + D + HID)
+    h = _rand_lp((M, D), g, 0)
+    w1 = _rand_lp((HID, D), g, 0, D ** -0.5)
+    w2 = _rand_lp((D, HID), g, 0, HID ** -0.5)
+    b1 = (torch.randn(HID, generator=g) * 0.1).to(DEV)
+    b2 = (torch.randn(D, generator=g) * 0.1).to(DEV)
+    xres = torch.randn(M, D, generator=g).to(DEV)
+    assert ops.mlp_supported(D, HID, BF16) and not ops.mlp_supported(D, HID, F32) and not ops.mlp_supported(320, HID, BF16)
+    v2, _, g2 = ops.gemm(h, w1, bias=b1, act=ACT_GELU, want_pre=train, flags=GEMM_PRE_IS_GRAD)
+    _, x2, _ = ops.gemm(v2, w2, bias=b2, res=xres, want_lp=False, want_f32=True)
+    x1, v1, g1 = ops.mlp_fwd(h, w1, b1, w2, b2, xres, train)
+    u = h.double() @ w1.double().t() + b1.double()
+    vref = torch.nn.functional.gelu(u)
+    xref = xres.double() + vref.bfloat16().double() @ w2.double().t() + b2.double()
+    e1 = (x1.double() - xref).abs().max().item()
+    e2 = (x2.double() - xref).abs().max().item()
+    assert e1 < 2e-2 and e1 < 2.0 * e2 + 2e-3, (e1, e2)
+    torch.testing.assert_close(x1, x2, rtol=0, atol=2e-2)
+    if train:
+        torch.testing.assert_close(v1.double(), vref, rtol=1e-2, atol=1e-2)
+        ud = u.clone().requires_grad_(True)
+        torch.nn.functional.gelu(ud).sum().backward()
+        torch.testing.assert_close(g1.double(), ud.grad, rtol=1e-2, atol=1e-2)
+        assert (v1 != v2).float().mean().item() < 2e-3 and (g1 != g2).float().mean().item() < 2e-3      # 1-ulp flips only
+    else:
+        assert v1 is None and g1 is None
+        xin = xres.clone()
+        x3, _, _ = ops.mlp_fwd(h, w1, b1, w2, b2, xin, False, out=xin)
+        assert x3.data_ptr() == xin.data_ptr() and torch.equal(x3, x1)
+    again, _, _ = ops.mlp_fwd(h, w1, b1, w2, b2, xres, train)
+    assert torch.equal(again, x1)
+
+
+def test_mlp_fwd_rejects_unsupported_shapes():
+    from star_amd import _lib as L_
+    lib = L_.lib()
+    t = torch.zeros(64, 320, device=DEV, dtype=torch.bfloat16)
+    rc = lib.star_mlp_fwd(t.data_ptr(), t.data_ptr(), t.data_ptr(), t.data_ptr(), t.data_ptr(), t.data_ptr(), t.data_ptr(), None, None,
+                          64, 320, 64, 0, None)
+    assert rc != 0 and "unsupported" in lib.star_last_error().decode()
+
+
 @pytest.mark.parametrize("dt", [0, 1])
 @pytest.mark.parametrize("m,n,k", [(256, 128, 384), (70, 32, 96)])        # the fast kernel's shape and a generic-kernel shape
 def test_relu_epilogue_keeps_nan_like_torch_relu(dt, m, n, k):
