@@ -459,6 +459,19 @@ __global__ void attn_delta_kernel(const T* __restrict__ out, const T* __restrict
 }
 
 
+// sum_j o[j] * d[j] over 8 bf16 pairs as one fma chain in element order: the dQ kernel (which folds the row dots into its
+// prologue) and attn_delta_bf16_kernel (the fused backward's table pass) follow the same operation sequence, bit for bit:
+// half0 = chain over elements 16 ks + 0..7 (ks ascending), half1 = chain over 16 ks + 8..15, dot = half0 + half1
+__device__ __forceinline__ float attn_dot8(uint4 o, uint4 d, float acc) {
+    const unsigned x[4] = {o.x, o.y, o.z, o.w}, y[4] = {d.x, d.y, d.z, d.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        acc = __builtin_fmaf(__uint_as_float(x[k] << 16), __uint_as_float(y[k] << 16), acc);
+        acc = __builtin_fmaf(__uint_as_float(x[k] & 0xffff0000u), __uint_as_float(y[k] & 0xffff0000u), acc);
+    }
+    return acc;
+}
+
 // bf16 path of the same, coalesced on both sides: a block takes 64 consecutive rows of one sequence, reads them as they lie
 // in memory (a thread = one (row, head) = HD bf16 of O and dO in 16-byte loads, all in flight), transposes the sums through
 // LDS and writes [head][row] runs of 256 bytes (the per-thread version scattered 4-byte stores L*4 bytes apart).
@@ -480,16 +493,13 @@ __global__ __launch_bounds__(256) void attn_delta_bf16_kernel(const bf16_t* __re
             a[j] = *reinterpret_cast<const uint4*>(out + base + j * 8);
             b[j] = *reinterpret_cast<const uint4*>(dout + base + j * 8);
         }
-        float sum = 0.f;
+        float half0 = 0.f, half1 = 0.f;
 #pragma unroll
-        for (int j = 0; j < HD / 8; ++j) {
-            const unsigned x[4] = {a[j].x, a[j].y, a[j].z, a[j].w}, y[4] = {b[j].x, b[j].y, b[j].z, b[j].w};
-#pragma unroll
-            for (int k = 0; k < 4; ++k)
-                sum += __uint_as_float(x[k] << 16) * __uint_as_float(y[k] << 16) +
-                       __uint_as_float(x[k] & 0xffff0000u) * __uint_as_float(y[k] & 0xffff0000u);
+        for (int j = 0; j < HD / 8; j += 2) {
+            half0 = attn_dot8(a[j], b[j], half0);
+            half1 = attn_dot8(a[j + 1], b[j + 1], half1);
         }
-        dl_tile[h * 65 + r] = sum;
+        dl_tile[h * 65 + r] = half0 + half1;
     }
     __syncthreads();
     for (int j = threadIdx.x; j < H * 64; j += 256) {
@@ -504,9 +514,10 @@ __global__ __launch_bounds__(256) void attn_delta_bf16_kernel(const bf16_t* __re
 // dQ: query on the lane (the forward's skeleton and ring).  Stage = K image | V image; K is read by rows for S
 // and transposed for dQ^T += K^T dS^T from the same image.  Keys past L need no mask: their K rows are zero.
 template <int HD>
-__global__ __launch_bounds__(AT) void attn_bwd_dq_bf16_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout,
-                                                              const float* __restrict__ lse, const float* __restrict__ ndelta,
-                                                              bf16_t* __restrict__ dqkv, int L, int H, float c, float scale) {
+__global__ __launch_bounds__(AT) void attn_bwd_dq_bf16_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ out,
+                                                              const bf16_t* __restrict__ dout, const float* __restrict__ lse,
+                                                              float* __restrict__ ndelta_out, float* __restrict__ nlsc_out,
+                                                              bf16_t* __restrict__ dqkv, int L, int H, float c, float scale, float inv_c) {
     using C = ACfg<HD>;
     constexpr int NI = 2 * C::NP / 4;
     constexpr int STAGE = 2 * C::TILE;
@@ -522,19 +533,33 @@ __global__ __launch_bounds__(AT) void attn_bwd_dq_bf16_kernel(const bf16_t* __re
     const bf16_t* qb = qkv + (int64_t)nb * L * rs + h * HD;
     const int q0 = rblk * 128 + wave * 32;
     const int q = q0 + r;
+    // The row dots delta = sum_d dO . O are computed HERE (each lane half over its 8 of every 16 head dims, the halves exchanged
+    // once) instead of by a table pass in front of the backward; the lanes of half 0 leave -delta and -lse / c in the tables the
+    // dK/dV kernel (launched behind this one) starts its accumulators from.
     short8_t qf[C::KS], dof[C::KS];
-    float ls = INFINITY, ndl = 0.f;
+    float ls = INFINITY, part = 0.f;
 #pragma unroll
     for (int ks = 0; ks < C::KS; ++ks) {
         qf[ks] = dof[ks] = (short8_t){0, 0, 0, 0, 0, 0, 0, 0};
         if (q < L) {
+            const int64_t ro = ((int64_t)nb * L + q) * H * HD + h * HD + ks * 16 + 8 * h2;
             qf[ks] = *reinterpret_cast<const short8_t*>(qb + (int64_t)q * rs + ks * 16 + 8 * h2);
-            dof[ks] = *reinterpret_cast<const short8_t*>(dout + ((int64_t)nb * L + q) * H * HD + h * HD + ks * 16 + 8 * h2);
+            dof[ks] = *reinterpret_cast<const short8_t*>(dout + ro);
+            part = attn_dot8(*reinterpret_cast<const uint4*>(out + ro), __builtin_bit_cast(uint4, dof[ks]), part);
         }
     }
-    if (q < L) {
-        ls = lse[((int64_t)nb * H + h) * L + q];
-        ndl = ndelta[((int64_t)nb * H + h) * L + q];
+    if (q < L) ls = lse[((int64_t)nb * H + h) * L + q];
+    float ndl;
+    {
+        typedef __attribute__((ext_vector_type(2))) unsigned u2;
+        const unsigned u = __float_as_uint(part);
+        const u2 sw = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+        // sw = (lanes 0-31: [own, partner's], lanes 32-63: [partner's, own]) -> half0 + half1 on every lane
+        ndl = -(__uint_as_float(sw[0]) + __uint_as_float(sw[1]));
+    }
+    if (h2 == 0 && q < L) {
+        ndelta_out[((int64_t)nb * H + h) * L + q] = ndl;
+        nlsc_out[((int64_t)nb * H + h) * L + q] = -ls * inv_c;
     }
 #pragma unroll
     for (int ks = 0; ks < C::KS; ++ks) {
@@ -1243,16 +1268,16 @@ static int fwd_bf16(const void* qkv, void* out, float* lse, int NB, int L, int H
     return 0;
 }
 template <int HD>
-static int bwd_bf16(const void* qkv, const void* dout, const float* lse, const float* ws, void* dqkv, int NB, int L, int H, float c,
-                    float scale, hipStream_t s) {
+static int bwd_bf16(const void* qkv, const void* out, const void* dout, const float* lse, const float* ws, void* dqkv, int NB, int L, int H,
+                    float c, float scale, hipStream_t s) {
     const float* delta = ws;                           // negated
     const float* nlsc = ws + (int64_t)NB * H * L;
     const size_t lds_q = 3 * 2 * ACfg<HD>::TILE;
     const size_t lds_kv = 3 * (2 * ACfg<HD>::TILE + 512);
     if (int rc = set_lds(attn_bwd_dq_bf16_kernel<HD>, lds_q)) return rc;
     if (int rc = set_lds(attn_bwd_dkv_bf16_kernel<HD>, lds_kv)) return rc;
-    hipLaunchKernelGGL(attn_bwd_dq_bf16_kernel<HD>, dim3(cdiv(L, 128) * H * NB), dim3(AT), lds_q, s, (const bf16_t*)qkv, (const bf16_t*)dout, lse,
-                       delta, (bf16_t*)dqkv, L, H, c, scale);
+    hipLaunchKernelGGL(attn_bwd_dq_bf16_kernel<HD>, dim3(cdiv(L, 128) * H * NB), dim3(AT), lds_q, s, (const bf16_t*)qkv, (const bf16_t*)out,
+                       (const bf16_t*)dout, lse, const_cast<float*>(delta), const_cast<float*>(nlsc), (bf16_t*)dqkv, L, H, c, scale, 1.0f / c);
     hipLaunchKernelGGL(attn_bwd_dkv_bf16_kernel<HD>, dim3(cdiv(L, 128) * H * NB), dim3(AT), lds_kv, s, (const bf16_t*)qkv, (const bf16_t*)dout, nlsc,
                        delta, (bf16_t*)dqkv, L, H, c, scale);
     return 0;
@@ -1349,17 +1374,20 @@ static int attn_bwd_impl(const void* qkv, const void* out, const void* dout, con
     const int64_t items = (int64_t)NB * L * H;
     int rc = 0;
     if (dt == STAR_BF16) {
-        const dim3 dgrid(NB * cdiv(L, 64));
-        const size_t dlds = (size_t)H * 65 * sizeof(float);
-        if (hd == 16) hipLaunchKernelGGL(attn_delta_bf16_kernel<16>, dgrid, dim3(256), dlds, s, (const bf16_t*)out, (const bf16_t*)dout, lse, delta, NB, L, H, 1.0f / c);
-        else if (hd == 32) hipLaunchKernelGGL(attn_delta_bf16_kernel<32>, dgrid, dim3(256), dlds, s, (const bf16_t*)out, (const bf16_t*)dout, lse, delta, NB, L, H, 1.0f / c);
-        else hipLaunchKernelGGL(attn_delta_bf16_kernel<64>, dgrid, dim3(256), dlds, s, (const bf16_t*)out, (const bf16_t*)dout, lse, delta, NB, L, H, 1.0f / c);
-        STAR_LAUNCH_CHECK("star_attn_bwd(delta)");
-        if (dq_part && hd == 16) rc = bwd_fused_bf16<16>(qkv, dout, delta, dq_part, dqkv, NB, L, H, c, scale, s);
-        else if (dq_part && hd == 32) rc = bwd_fused_bf16<32>(qkv, dout, delta, dq_part, dqkv, NB, L, H, c, scale, s);
-        else if (hd == 16) rc = bwd_bf16<16>(qkv, dout, lse, delta, dqkv, NB, L, H, c, scale, s);
-        else if (hd == 32) rc = bwd_bf16<32>(qkv, dout, lse, delta, dqkv, NB, L, H, c, scale, s);
-        else rc = bwd_bf16<64>(qkv, dout, lse, delta, dqkv, NB, L, H, c, scale, s);
+        const bool fused = dq_part != nullptr && hd <= 32;
+        if (fused) {   // the single-sweep kernel reads both row-constant tables: one pass in front of it writes them
+            const dim3 dgrid(NB * cdiv(L, 64));
+            const size_t dlds = (size_t)H * 65 * sizeof(float);
+            if (hd == 16) hipLaunchKernelGGL(attn_delta_bf16_kernel<16>, dgrid, dim3(256), dlds, s, (const bf16_t*)out, (const bf16_t*)dout, lse, delta, NB, L, H, 1.0f / c);
+            else hipLaunchKernelGGL(attn_delta_bf16_kernel<32>, dgrid, dim3(256), dlds, s, (const bf16_t*)out, (const bf16_t*)dout, lse, delta, NB, L, H, 1.0f / c);
+            STAR_LAUNCH_CHECK("star_attn_bwd(delta)");
+            rc = hd == 16 ? bwd_fused_bf16<16>(qkv, dout, delta, dq_part, dqkv, NB, L, H, c, scale, s)
+                          : bwd_fused_bf16<32>(qkv, dout, delta, dq_part, dqkv, NB, L, H, c, scale, s);
+        }
+        // two kernels: the dQ kernel computes the row dots in its prologue and leaves the tables for the dK/dV kernel behind it
+        else if (hd == 16) rc = bwd_bf16<16>(qkv, out, dout, lse, delta, dqkv, NB, L, H, c, scale, s);
+        else if (hd == 32) rc = bwd_bf16<32>(qkv, out, dout, lse, delta, dqkv, NB, L, H, c, scale, s);
+        else rc = bwd_bf16<64>(qkv, out, dout, lse, delta, dqkv, NB, L, H, c, scale, s);
     } else {
         hipLaunchKernelGGL((attn_delta_kernel<float, false>), dim3(cdiv(items, 256)), dim3(256), 0, s, (const float*)out, (const float*)dout, lse, delta, NB, L, H, hd, 1.0f / c);
         STAR_LAUNCH_CHECK("star_attn_bwd(delta)");
