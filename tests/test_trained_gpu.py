@@ -174,9 +174,17 @@ def test_full_size_trained_model_both_modes_against_oracle():
         if dtype == "fp32":
             assert abs(loss.item() - ol.item()) < 1e-6
             assert pe.max().item() < 1e-3                                      # measured 1.2e-4 .. 2.6e-4 at |logit| <= 15
-            assert not flips.any()
-            assert np.array_equal(result.cpu().numpy(), ores.numpy())
-            assert np.array_equal(_iou(result.cpu(), teacher), oiou)
+            # identical decisions wherever the oracle's margin exceeds the logit error bound; the weights come out of a bf16
+            # training run on the GPU, so whether one of the 2.6 M voxels sits within 1e-3 of a tie differs from build to build
+            assert not flips.any() or margin[flips].max() < 1e-3, (int(flips.sum()), float(margin[flips].max()))
+            if not flips.any():
+                assert np.array_equal(result.cpu().numpy(), ores.numpy())
+                assert np.array_equal(_iou(result.cpu(), teacher), oiou)
+            else:       # a handful of exact near-ties: the fusion of MY decisions must still be the oracle's fusion of them
+                assert flips.sum() <= 20, int(flips.sum())
+                want = O.late_fusion(ind.cpu().numpy().astype(np.float32), data["trans_matrices"].numpy(), data["num_agent"].numpy(), 1)
+                assert np.array_equal(result.cpu().numpy(), np.asarray(want))
+                assert np.abs(_iou(result.cpu(), teacher) - oiou).max() < 5e-4      # 3 fused voxels of ~36 k occupied ones
             assert max(rel.values()) < 1e-3, max(rel.items(), key=lambda kv: kv[1])     # measured 1.1e-5
         else:
             assert abs(loss.item() - ol.item()) < 1e-4                         # measured 1e-6
