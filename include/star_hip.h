@@ -84,6 +84,19 @@ int64_t star_layernorm_bwd_ws(int D);
 int star_layernorm_bwd(const void* dy, const float* x, const float* gamma, const float* mean,
                        const float* rstd, const float* g_in, float* g_out, void* g_out_lp, float* dgamma,
                        float* dbeta, float* ws, int M, int D, int dt, void* stream);
+/* Deferred parameter gradients: star_layernorm_bwd with dgamma = dbeta = NULL leaves its partial rows in `ws`
+ * (star_layernorm_fold_rows(M) rows of 2*D floats); star_layernorm_fold_batch folds the rows of many such calls in ONE launch
+ * (bit-identical to the immediate fold).  `jobs` is a device array.  Same op as above (autograd backward of nn.LayerNorm): a
+ * training step's 22 LayerNorm parameter gradients feed nothing in the backward chain, and 22 five-microsecond launches leave it. */
+typedef struct StarLnFoldJob {
+    const float* ws;
+    float* dgamma;
+    float* dbeta;
+    int32_t nb;      /* star_layernorm_fold_rows(M) of the call that filled ws */
+    int32_t D;
+} StarLnFoldJob;
+int star_layernorm_fold_rows(int M);
+int star_layernorm_fold_batch(const StarLnFoldJob* jobs, int njobs, int max_D, void* stream);
 
 /* Allocation-free variant of star_layernorm_bwd.  It has NO counterpart in the reference: it exists for callers that
  * cannot allocate device memory or bring a workspace (code under HIP graph capture, tight serving loops, harnesses

@@ -42,6 +42,8 @@ _SIGS = {
     "star_layernorm_fwd": (C.c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _F, _I, _P]),
     "star_layernorm_bwd_ws": (C.c_int64, [_I]),
     "star_layernorm_bwd": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
+    "star_layernorm_fold_rows": (C.c_int, [_I]),
+    "star_layernorm_fold_batch": (C.c_int, [_P, _I, _I, _P]),
     "star_layernorm_bwd_static": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "star_gemm": (C.c_int, [C.POINTER(StarGemm), _P]),
     "star_gemm_wgrad_ws": (C.c_int64, [_I, _I, _I]),

@@ -230,8 +230,53 @@ static int ln_bwd_launch(const void* dy, const float* x, const float* gamma, con
     const int nvec = (D / 4 + 63) / 64;
     if (nvec <= 1) LN_BWD(1); else if (nvec == 2) LN_BWD(2); else if (nvec == 3) LN_BWD(3); else if (nvec == 4) LN_BWD(4); else LN_BWD(LN_MAXV);
     STAR_LAUNCH_CHECK("star_layernorm_bwd");
+    if (dgamma == nullptr && dbeta == nullptr) return 0;   // deferred: the partial rows stay in ws for star_layernorm_fold_batch
     hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3(cdiv(2 * D, 16)), dim3(1024), 0, (hipStream_t)stream, ws, dgamma, dbeta, nb, D);
     STAR_LAUNCH_CHECK("star_layernorm_bwd(reduce)");
+    return 0;
+}
+
+// The folds of MANY LayerNorm backward calls in one launch (grid.y = job): a training step has 22 LayerNorms whose dgamma / dbeta
+// nothing in the backward chain waits for; each fold is a 5 us launch on the critical path when issued beside its LayerNorm.
+__global__ __launch_bounds__(1024) void ln_fold_batch_kernel(const StarLnFoldJob* __restrict__ jobs) {
+    const StarLnFoldJob j = jobs[blockIdx.y];
+    const int D = j.D, nblocks = j.nb;
+    if ((int)blockIdx.x * 16 >= 2 * D) return;
+    const float* __restrict__ ws = j.ws;
+    __shared__ float s[64][17];
+    const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
+    const int e = blockIdx.x * 16 + cl;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    if (e < 2 * D) {      // the summation order of ln_bwd_reduce_kernel: the batched fold is bit-identical to the immediate one
+        int b = rl;
+        for (; b + 192 < nblocks; b += 256) {
+            a0 += ws[(size_t)b * 2 * D + e];
+            a1 += ws[(size_t)(b + 64) * 2 * D + e];
+            a2 += ws[(size_t)(b + 128) * 2 * D + e];
+            a3 += ws[(size_t)(b + 192) * 2 * D + e];
+        }
+        for (; b < nblocks; b += 64) a0 += ws[(size_t)b * 2 * D + e];
+    }
+    s[rl][cl] = (a0 + a1) + (a2 + a3);
+    __syncthreads();
+    if (rl == 0 && e < 2 * D) {
+        float a = 0.f;
+#pragma unroll
+        for (int r = 0; r < 64; ++r) a += s[r][cl];
+        if (e < D) j.dgamma[e] = a;
+        else j.dbeta[e - D] = a;
+    }
+}
+
+extern "C" int star_layernorm_fold_rows(int M) {
+    int nb = cdiv(M, LN_BWD_THREADS / 64);
+    return nb > LN_BWD_BLOCKS ? LN_BWD_BLOCKS : nb;
+}
+
+extern "C" int star_layernorm_fold_batch(const StarLnFoldJob* jobs_dev, int njobs, int max_D, void* stream) {
+    STAR_CHECK(jobs_dev && njobs > 0 && njobs <= 65535 && max_D >= 4, "star_layernorm_fold_batch: bad arguments (njobs=%d max_D=%d)", njobs, max_D);
+    hipLaunchKernelGGL(ln_fold_batch_kernel, dim3(cdiv(2 * max_D, 16), njobs), dim3(1024), 0, (hipStream_t)stream, jobs_dev);
+    STAR_LAUNCH_CHECK("star_layernorm_fold_batch");
     return 0;
 }
 

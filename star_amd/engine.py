@@ -181,13 +181,16 @@ def _put(grads, G, name, val):
 
 def stages(cfg):
     """Parameter names grouped in the order their gradients complete in backward(); only parameters the
-    configured path really uses (the others never receive a gradient, reference Q5)."""
-    blk = ["norm1.weight", "norm1.bias", "attn.qkv.weight", "attn.qkv.bias", "attn.proj.weight", "attn.proj.bias",
-           "norm2.weight", "norm2.bias", "mlp.fc1.weight", "mlp.fc1.bias", "mlp.fc2.weight", "mlp.fc2.bias"]
-    out = [["decoder_pred_occ.weight", "decoder_pred_occ.bias", "decoder_pred_free.weight", "decoder_pred_free.bias",
-            "decoder_norm.weight", "decoder_norm.bias"]]
+    configured path really uses (the others never receive a gradient, reference Q5).  Every LayerNorm weight / bias sits in the
+    LAST stage: their gradients are folded by one launch at the end of the backward (_LnFolds)."""
+    blk = ["attn.qkv.weight", "attn.qkv.bias", "attn.proj.weight", "attn.proj.bias",
+           "mlp.fc1.weight", "mlp.fc1.bias", "mlp.fc2.weight", "mlp.fc2.bias"]
+    lnb = ["norm1.weight", "norm1.bias", "norm2.weight", "norm2.bias"]
+    norms = ["decoder_norm.weight", "decoder_norm.bias"]
+    out = [["decoder_pred_occ.weight", "decoder_pred_occ.bias", "decoder_pred_free.weight", "decoder_pred_free.bias"]]
     for i in reversed(range(cfg.ddepth)):
         out.append(["decoder_blocks.%d.%s" % (i, n) for n in blk])
+        norms += ["decoder_blocks.%d.%s" % (i, n) for n in lnb]
     mid = []
     if cfg.mask == "random" or cfg.decode_singletemp:
         mid.append("mask_token")
@@ -196,11 +199,13 @@ def stages(cfg):
     mid += ["decoder_embed.weight", "decoder_embed.bias", "decompressor.weight", "decompressor.bias"]
     if getattr(cfg, "vq", False) and not getattr(cfg, "vq_decay", 0.0) > 0.0:     # an EMA codebook is not a trained parameter
         mid.append("_vq_star._embedding.weight")
-    mid += ["compressor.0.weight", "compressor.0.bias", "norm.weight", "norm.bias"]
+    mid += ["compressor.0.weight", "compressor.0.bias"]
+    norms += ["norm.weight", "norm.bias"]
     out.append(mid)
     for i in reversed(range(cfg.depth)):
         out.append(["blocks.%d.%s" % (i, n) for n in blk])
-    out.append(["patch_embed.proj.weight", "patch_embed.proj.bias"])
+        norms += ["blocks.%d.%s" % (i, n) for n in lnb]
+    out.append(["patch_embed.proj.weight", "patch_embed.proj.bias"] + norms)
     return out
 
 
@@ -252,12 +257,47 @@ def _wg(grads, G, name, dy, x, x_rows=None, side=None):
     grads[name + ".weight"], grads[name + ".bias"] = dw, db
 
 
-def _ln_bwd(grads, G, name, dy, x, P, mean, rstd, g_in=None):
-    g, g_lp, dgam, dbet = ops.layernorm_bwd(dy, x, P[name + ".weight"], mean, rstd, g_in=g_in,
-                                            dgamma=None if G is None else G[name + ".weight"],
-                                            dbeta=None if G is None else G[name + ".bias"])
+def _ln_bwd(grads, G, name, dy, x, P, mean, rstd, g_in=None, fold=None):
+    """LayerNorm backward.  `fold` (an _LnFolds): the dgamma / dbeta fold is deferred to ONE launch at the end of the backward."""
+    kw = dict(g_in=g_in, dgamma=None if G is None else G[name + ".weight"], dbeta=None if G is None else G[name + ".bias"])
+    if fold is not None and G is not None:
+        kw["defer_ws"] = fold.workspace(name, x)
+    g, g_lp, dgam, dbet = ops.layernorm_bwd(dy, x, P[name + ".weight"], mean, rstd, **kw)
+    if fold is not None and G is not None:
+        fold.add(name, dgam, dbet, x)
     grads[name + ".weight"], grads[name + ".bias"] = dgam, dbet
     return g, g_lp
+
+
+class _LnFolds:
+    """The deferred dgamma / dbeta folds of one backward pass: a persistent workspace per LayerNorm (kept on the model's Weights
+    object: 2.4 MB each at D = 384) and a device job table that is rebuilt only when a pointer or a row count changes."""
+
+    def __init__(self, W):
+        self.W = W
+        if not hasattr(W, "ln_ws"):
+            W.ln_ws, W.ln_table = {}, None
+        self.jobs = []
+
+    def workspace(self, name, x):
+        need = ops.L.lib().star_layernorm_bwd_ws(x.shape[1])
+        ws = self.W.ln_ws.get(name)
+        if ws is None or ws.numel() < need or ws.device != x.device:
+            ws = self.W.ln_ws[name] = torch.empty(need, dtype=torch.float32, device=x.device)
+        return ws
+
+    def add(self, name, dgam, dbet, x):
+        self.jobs.append((self.W.ln_ws[name], dgam, dbet, x.shape[0], x.shape[1]))
+
+    def run(self):
+        if not self.jobs:
+            return
+        sig = tuple((j[0].data_ptr(), j[1].data_ptr(), j[2].data_ptr(), j[3], j[4]) for j in self.jobs)
+        if self.W.ln_table is None or self.W.ln_table[0] != sig:
+            self.W.ln_table = (sig,) + ops.ln_fold_table(self.jobs, self.jobs[0][0].device)
+        _, tab, n, max_d = self.W.ln_table
+        ops.ln_fold_batch(tab, n, max_d)
+        self.jobs = []
 
 
 # The fc2 weight gradient of a block is queued on the side stream right before the block's attention backward (compute-bound, the
@@ -267,9 +307,10 @@ WG_DEFER = os.environ.get("STAR_AMD_WG_DEFER", "1") == "1"
 # the weight gradients outside the blocks (prediction heads, decoder_embed, decompressor, compressor) run on the side stream too:
 # A/B inside one GPU call 13.51 -> 13.35 ms/step
 SIDE_EXTRA = os.environ.get("STAR_AMD_SIDE_EXTRA", "1") == "1"
+LN_FOLD_BATCH = os.environ.get("STAR_AMD_LN_FOLD_BATCH", "1") == "1"   # 0: every LayerNorm folds its dgamma / dbeta rows at once (A/B)
 
 
-def _block_bwd(g, g_lp, s, P, W, dt, grads, G=None, side=None):
+def _block_bwd(g, g_lp, s, P, W, dt, grads, G=None, side=None, fold=None):
     pre = s["pre"]
     heads, nb, l = s["heads"], s["nb"], s["l"]
     hd = s["x"].shape[1] // heads
@@ -279,7 +320,7 @@ def _block_bwd(g, g_lp, s, P, W, dt, grads, G=None, side=None):
     du, _, _ = ops.gemm(g_lp, _lin(P, W, pre + "mlp.fc2", dt, True), act=ACT_MULAUX, aux=s["u"])
     _wg(grads, G, pre + "mlp.fc1", du, s["h2"], side=side)
     dh2, _, _ = ops.gemm(du, _lin(P, W, pre + "mlp.fc1", dt, True))
-    g1, g1_lp = _ln_bwd(grads, G, pre + "norm2", dh2, s["x_mid"], P, s["mean2"], s["rstd2"], g_in=g)
+    g1, g1_lp = _ln_bwd(grads, G, pre + "norm2", dh2, s["x_mid"], P, s["mean2"], s["rstd2"], g_in=g, fold=fold)
     _wg(grads, G, pre + "attn.proj", g1_lp, s["a"], side=side)
     da, _, _ = ops.gemm(g1_lp, _lin(P, W, pre + "attn.proj", dt, True))
     for a, k in late:          # the held-back fc2 weight gradient starts beside the attention backward
@@ -287,7 +328,7 @@ def _block_bwd(g, g_lp, s, P, W, dt, grads, G=None, side=None):
     dqkv = ops.attn_bwd(s["qkv"], s["a"], da, s["lse"], nb, l, heads, hd)
     _wg(grads, G, pre + "attn.qkv", dqkv, s["h1"], side=side)
     dh1, _, _ = ops.gemm(dqkv, _lin(P, W, pre + "attn.qkv", dt, True))
-    g0, g0_lp = _ln_bwd(grads, G, pre + "norm1", dh1, s["x"], P, s["mean1"], s["rstd1"], g_in=g1)
+    g0, g0_lp = _ln_bwd(grads, G, pre + "norm1", dh1, s["x"], P, s["mean1"], s["rstd1"], g_in=g1, fold=fold)
     return g0, g0_lp
 
 
@@ -434,6 +475,7 @@ def backward(cfg, P, W, dt, ctx, G=None, on_ready=None):
     save = ctx["save"]
     dlog = ctx["dlogits"]
     side = _SideStream(dlog.device) if SIDE_STREAM and G is not None else None
+    fold = _LnFolds(W) if G is not None and LN_FOLD_BATCH else None      # flat gradient buffer: all LayerNorm folds in one launch at the end
     # prediction heads: weight gradient (and its row permutation back to the reference order) beside the dgrad chain
     side_x = side if SIDE_EXTRA else None
 
@@ -453,14 +495,14 @@ def backward(cfg, P, W, dt, ctx, G=None, on_ready=None):
     else:
         side_x.run(heads_wgrad, dlog, ctx["yd"])
     dyd, _, _ = ops.gemm(dlog, _heads(P, W, cfg, dt, True))
-    g, g_lp = _ln_bwd(grads, G, "decoder_norm", dyd, ctx["xd"], P, ctx["mean_d"], ctx["rstd_d"])
+    g, g_lp = _ln_bwd(grads, G, "decoder_norm", dyd, ctx["xd"], P, ctx["mean_d"], ctx["rstd_d"], fold=fold)
     stage = 0
     if on_ready is not None:
         if side_x is not None:
             side_x.join()
         on_ready(stage)
     for s in reversed(save[cfg.depth:]):
-        g, g_lp = _block_bwd(g, g_lp, s, P, W, dt, grads, G, side)
+        g, g_lp = _block_bwd(g, g_lp, s, P, W, dt, grads, G, side, fold)
         stage += 1
         if on_ready is not None:
             if side is not None:
@@ -499,14 +541,14 @@ def backward(cfg, P, W, dt, ctx, G=None, on_ready=None):
     _wg(grads, G, "compressor.0", dlat, ctx["y"], x_rows=comp_rows, side=side_x)
     rows_enc = n_frames * ctx["l_enc"]
     dy, _, _ = ops.gemm(dlat, _lin(P, W, "compressor.0", dt, True), c_rows=comp_rows, out_rows=rows_enc)
-    g, g_lp = _ln_bwd(grads, G, "norm", dy, ctx["x_enc"], P, ctx["mean_e"], ctx["rstd_e"])
+    g, g_lp = _ln_bwd(grads, G, "norm", dy, ctx["x_enc"], P, ctx["mean_e"], ctx["rstd_e"], fold=fold)
     stage += 1
     if on_ready is not None:
         if side_x is not None:
             side_x.join()
         on_ready(stage)
     for s in reversed(save[:cfg.depth]):
-        g, g_lp = _block_bwd(g, g_lp, s, P, W, dt, grads, G, side)
+        g, g_lp = _block_bwd(g, g_lp, s, P, W, dt, grads, G, side, fold)
         stage += 1
         if on_ready is not None:
             if side is not None:
@@ -523,6 +565,8 @@ def backward(cfg, P, W, dt, ctx, G=None, on_ready=None):
         dw = dw.reshape(wshape[0], wshape[2], wshape[3], wshape[1]).permute(0, 3, 1, 2).contiguous()
     _put(grads, G, "patch_embed.proj.weight", dw.reshape(wshape))
     _put(grads, G, "patch_embed.proj.bias", db)
+    if fold is not None:
+        fold.run()
     if side is not None:
         side.join()
     if on_ready is not None:

@@ -139,8 +139,9 @@ def layernorm_fwd(x, gamma, beta, eps, dt, want_stats=True):
     return y, mean, rstd
 
 
-def layernorm_bwd(dy, x, gamma, mean, rstd, g_in=None, want_lp=True, g_out=None, dgamma=None, dbeta=None):
-    """-> (g_out float32 [M,D] = g_in + dx, g_lp copy in dy's dtype or None, dgamma, dbeta)."""
+def layernorm_bwd(dy, x, gamma, mean, rstd, g_in=None, want_lp=True, g_out=None, dgamma=None, dbeta=None, defer_ws=None):
+    """-> (g_out float32 [M,D] = g_in + dx, g_lp copy in dy's dtype or None, dgamma, dbeta).  defer_ws: a caller-kept workspace;
+    the partial dgamma / dbeta rows are left in it for ln_fold_batch and dgamma / dbeta are NOT written by this call."""
     m, d = x.shape
     dt = L.dt_of(dy)
     assert dy.is_contiguous() and x.is_contiguous()
@@ -151,11 +152,27 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, g_in=None, want_lp=True, g_out=None,
         dgamma = torch.empty(d, dtype=torch.float32, device=x.device)
     if dbeta is None:
         dbeta = torch.empty(d, dtype=torch.float32, device=x.device)
-    ws = torch.empty(L.lib().star_layernorm_bwd_ws(d), dtype=torch.float32, device=x.device)
+    defer = defer_ws is not None
+    ws = defer_ws if defer else torch.empty(L.lib().star_layernorm_bwd_ws(d), dtype=torch.float32, device=x.device)
+    assert ws.numel() >= L.lib().star_layernorm_bwd_ws(d) and ws.dtype == torch.float32
     with _timed("layernorm_bwd", 0.0, float(m) * d * (4 + 4 + 4 + 2 * (2 if dt == BF16 else 4))):
-        L.check(L.lib().star_layernorm_bwd(p(dy), p(x), p(gamma), p(mean), p(rstd), p(g_in), p(g_out), p(g_lp), p(dgamma),
-                                           p(dbeta), p(ws), m, d, dt, L.stream()))
+        L.check(L.lib().star_layernorm_bwd(p(dy), p(x), p(gamma), p(mean), p(rstd), p(g_in), p(g_out), p(g_lp),
+                                           None if defer else p(dgamma), None if defer else p(dbeta), p(ws), m, d, dt, L.stream()))
     return g_out, g_lp, dgamma, dbeta
+
+
+def ln_fold_table(jobs, device):
+    """Device job table for ln_fold_batch: jobs = [(ws, dgamma, dbeta, M, D), ...] -> (table tensor, njobs, max D)."""
+    rec = np.zeros(len(jobs), dtype=np.dtype([("ws", "<u8"), ("dg", "<u8"), ("db", "<u8"), ("nb", "<i4"), ("D", "<i4")]))
+    for i, (ws, dg, db, m, d) in enumerate(jobs):
+        assert dg.is_contiguous() and db.is_contiguous() and dg.numel() == d and db.numel() == d
+        rec[i] = (ws.data_ptr(), dg.data_ptr(), db.data_ptr(), L.lib().star_layernorm_fold_rows(m), d)
+    tab = torch.from_numpy(rec.view(np.uint8).copy()).to(device)
+    return tab, len(jobs), max(j[4] for j in jobs)
+
+
+def ln_fold_batch(tab, njobs, max_d):
+    L.check(L.lib().star_layernorm_fold_batch(p(tab), njobs, max_d, L.stream()))
 
 
 # ---------------------------------------------------------------------------------------------------

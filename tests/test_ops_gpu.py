@@ -16,6 +16,7 @@ pytestmark = pytest.mark.gpu
 if torch.cuda.is_available():
     from oracle import star_oracle as O
     from star_amd import ops
+    from star_amd import _lib as L_mod
     from star_amd._lib import ACT_DGELU, ACT_DRELU, ACT_GELU, ACT_MULAUX, ACT_NONE, ACT_RELU, BF16, F32, GEMM_PRE_IS_GRAD
 
 DEV = "cuda"
@@ -627,3 +628,26 @@ def test_gemm_w_in_registers_path(M, N):
     eye[idx, idx % K] = 1
     lp, _, _ = ops.gemm(eye, w, want_lp=True, want_f32=False)
     assert torch.equal(lp, w.t()[idx % K])
+
+
+def test_layernorm_deferred_folds_in_one_launch_are_bit_identical():
+    """star_layernorm_bwd with dgamma = dbeta = NULL + star_layernorm_fold_batch over several calls (different M, D) against the
+    immediate fold of the same calls."""
+    g = torch.Generator().manual_seed(21)
+    jobs, want = [], []
+    for (m, d) in [(5000, 384), (333, 256), (40, 64), (9000, 384)]:
+        x = torch.randn(m, d, generator=g).to(DEV)
+        dy = torch.randn(m, d, generator=g).to(DEV).bfloat16()
+        gamma = torch.randn(d, generator=g).to(DEV)
+        mean, rstd = x.mean(1), (x.var(1, unbiased=False) + 1e-6).rsqrt()
+        g1, l1, dg1, db1 = ops.layernorm_bwd(dy, x, gamma, mean, rstd)
+        ws = torch.empty(L_mod.lib().star_layernorm_bwd_ws(d), dtype=torch.float32, device=DEV)
+        dg2, db2 = torch.full((d,), float("nan"), device=DEV), torch.full((d,), float("nan"), device=DEV)
+        g2, l2, _, _ = ops.layernorm_bwd(dy, x, gamma, mean, rstd, dgamma=dg2, dbeta=db2, defer_ws=ws)
+        assert torch.equal(g1, g2) and torch.equal(l1, l2) and torch.isnan(dg2).all()      # not written before the fold
+        jobs.append((ws, dg2, db2, m, d))
+        want.append((dg1, db1))
+    tab, n, max_d = ops.ln_fold_table(jobs, DEV)
+    ops.ln_fold_batch(tab, n, max_d)
+    for (ws, dg2, db2, m, d), (dg1, db1) in zip(jobs, want):
+        assert torch.equal(dg1, dg2) and torch.equal(db1, db2)
