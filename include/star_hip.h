@@ -150,6 +150,18 @@ int64_t star_gemm_wgrad_ws(int M, int N, int K);
 int star_gemm_wgrad(const void* dY, const void* X, const int32_t* x_rows, float* dW, float* db, float* ws,
                     int M, int N, int K, int dt, void* stream);
 
+/* ---- K3 + K2: the Linear that closes a residual branch and the LayerNorm that reads its result, one launch -------------
+ * Replaces, in timm 0.3.2 Block.forward (ctor mae_base.py:279-281,308-310), `x = x + proj(...)` / `x = x + fc2(...)` together
+ * with the LayerNorm applied to that x next (norm2, the next block's norm1, or self.norm / self.decoder_norm,
+ * mae_base.py:282,312):  x_out[M, N] (float32) = res + A W^T + bias;  h[M, N] (bf16) = LayerNorm_eps(x_out) * gamma + beta;
+ * mean / rstd [M] optional.  A [M, K], W [N, K] bf16; N = 256 or 384 (a tile spans whole rows), K % 32 == 0.  x_out may be res.
+ * star_gemm_res_ln_supported(N, K, dt) != 0 tells whether a kernel exists; other shapes -> error (callers launch star_gemm and
+ * star_layernorm_fwd instead). */
+int star_gemm_res_ln_supported(int N, int K, int dt);
+int star_gemm_res_ln(const void* A, const void* W, const float* bias, const float* res, float* x_out, const float* gamma,
+                     const float* beta, float eps, void* h, float* mean, float* rstd, int M, int N, int K, int dt,
+                     void* stream);
+
 /* ---- K3': the block's MLP forward as one kernel ---------------------------------------------------------
  * Replaces timm 0.3.2 Mlp.forward plus the block's second residual add (Block.forward: x = x + mlp(norm2(x)); ctor
  * mae_base.py:279-281,308-310): xout[M, D] (float32) = xres + fc2(gelu(fc1(h))) with h [M, D], w1 [HID, D], w2 [D, HID] in bf16

@@ -148,27 +148,59 @@ def _patch_weight(P, W, cfg, dt, channels_last):
 
 
 # -------------------------------------------------------------------------------------------------------
-def _block_fwd(x, P, W, pre, heads, nb, l, dt, eps, save, train):
+def _block_fwd(x, P, W, pre, heads, nb, l, dt, eps, save, train, ln1=None, nxt=None):
+    """One transformer block.  ln1: (h1, mean1, rstd1) when the kernel that produced x already normalised it; nxt: name of the
+    LayerNorm applied to this block's result (the next block's norm1 or the final norm) -- when given, returns (x_out, ln) with
+    ln = (h, mean, rstd) of that LayerNorm (from the fc2 kernel where star_gemm_res_ln covers the shape), else x_out alone."""
     d = x.shape[1]
     hd = d // heads
-    h1, mean1, rstd1 = ops.layernorm_fwd(x, P[pre + "norm1.weight"], P[pre + "norm1.bias"], eps, dt, want_stats=train)
+    fuse_ln = _GEMM_LN and ops.gemm_res_ln_supported(d, d, dt)
+    h1, mean1, rstd1 = ln1 if ln1 is not None else ops.layernorm_fwd(x, P[pre + "norm1.weight"], P[pre + "norm1.bias"], eps, dt, want_stats=train)
     qkv, _, _ = ops.gemm(h1, _lin(P, W, pre + "attn.qkv", dt), bias=P[pre + "attn.qkv.bias"])
     a, lse = ops.attn_fwd(qkv, nb, l, heads, hd)
-    _, x_mid, _ = ops.gemm(a, _lin(P, W, pre + "attn.proj", dt), bias=P[pre + "attn.proj.bias"], res=x, want_lp=False,
-                           want_f32=True, out_f32=None if train else x)
-    h2, mean2, rstd2 = ops.layernorm_fwd(x_mid, P[pre + "norm2.weight"], P[pre + "norm2.bias"], eps, dt, want_stats=train)
+    if fuse_ln:      # x_mid = x + proj(a) and norm2(x_mid) in one launch
+        x_mid, h2, mean2, rstd2 = ops.gemm_res_ln(a, _lin(P, W, pre + "attn.proj", dt), P[pre + "attn.proj.bias"], x, P[pre + "norm2.weight"],
+                                                  P[pre + "norm2.bias"], eps, want_stats=train, out=None if train else x)
+    else:
+        _, x_mid, _ = ops.gemm(a, _lin(P, W, pre + "attn.proj", dt), bias=P[pre + "attn.proj.bias"], res=x, want_lp=False,
+                               want_f32=True, out_f32=None if train else x)
+        h2, mean2, rstd2 = ops.layernorm_fwd(x_mid, P[pre + "norm2.weight"], P[pre + "norm2.bias"], eps, dt, want_stats=train)
     # u is not the pre-activation but gelu'(pre-activation): all the backward needs of it (flag PRE_IS_GRAD)
     w1, w2 = _lin(P, W, pre + "mlp.fc1", dt), _lin(P, W, pre + "mlp.fc2", dt)
+    ln = None
     if _MLP_FUSED and ops.mlp_supported(d, w1.shape[0], dt):
         x_out, v, u = ops.mlp_fwd(h2, w1, P[pre + "mlp.fc1.bias"], w2, P[pre + "mlp.fc2.bias"], x_mid, train, out=None if train else x_mid)
     else:
         v, _, u = ops.gemm(h2, w1, bias=P[pre + "mlp.fc1.bias"], act=ACT_GELU, want_pre=train, flags=GEMM_PRE_IS_GRAD)
-        _, x_out, _ = ops.gemm(v, w2, bias=P[pre + "mlp.fc2.bias"], res=x_mid, want_lp=False, want_f32=True,
-                               out_f32=None if train else x_mid)
+        if nxt is not None and _GEMM_LN and ops.gemm_res_ln_supported(d, w1.shape[0], dt):
+            x_out, hn, mean_n, rstd_n = ops.gemm_res_ln(v, w2, P[pre + "mlp.fc2.bias"], x_mid, P[nxt + ".weight"], P[nxt + ".bias"], eps,
+                                                        want_stats=train, out=None if train else x_mid)
+            ln = (hn, mean_n, rstd_n)
+        else:
+            _, x_out, _ = ops.gemm(v, w2, bias=P[pre + "mlp.fc2.bias"], res=x_mid, want_lp=False, want_f32=True,
+                                   out_f32=None if train else x_mid)
     if train:
         save.append(dict(pre=pre, x=x, mean1=mean1, rstd1=rstd1, h1=h1, qkv=qkv, a=a, lse=lse, x_mid=x_mid, mean2=mean2,
                          rstd2=rstd2, h2=h2, u=u, v=v, heads=heads, nb=nb, l=l))
-    return x_out
+    if nxt is None:
+        return x_out
+    if ln is None:
+        ln = ops.layernorm_fwd(x_out, P[nxt + ".weight"], P[nxt + ".bias"], eps, dt, want_stats=train)
+    return x_out, ln
+
+
+def _blocks_fwd(x, P, W, fmt, depth, norm, heads, nb, l, dt, eps, save, train, taps=None, tap=None):
+    """`depth` blocks named fmt % i and the LayerNorm `norm` behind them -> (x, y, mean, rstd).  Every LayerNorm but the first is
+    produced by the Linear in front of it (star_gemm_res_ln) where that kernel covers the shape."""
+    ln = None
+    for i in range(depth):
+        nxt = (fmt % (i + 1)) + "norm1" if i + 1 < depth else norm
+        x, ln = _block_fwd(x, P, W, fmt % i, heads, nb, l, dt, eps, save, train, ln1=ln, nxt=nxt)
+        if taps is not None:
+            taps[tap % i] = x.clone()
+    if ln is None:      # no blocks at all
+        ln = ops.layernorm_fwd(x, P[norm + ".weight"], P[norm + ".bias"], eps, dt, want_stats=train)
+    return (x,) + tuple(ln)
 
 
 def _put(grads, G, name, val):
@@ -240,6 +272,7 @@ class _SideStream:
             self.used = False
 
 
+_GEMM_LN = os.environ.get("STAR_AMD_GEMM_LN", "1") == "1"           # proj / fc2 + residual + the LayerNorm behind them in one launch (star_gemm_res_ln)
 _MLP_FUSED = os.environ.get("STAR_AMD_MLP_FUSED", "0") == "1"       # the block MLP forward as one kernel (star_mlp_fwd): measured slower, opt-in
 _SKIP_WGRAD = os.environ.get("STAR_AMD_SKIP_WGRAD", "0") == "1"   # measurement only (wrong gradients): the backward chain without its weight-gradient GEMMs
 
@@ -373,11 +406,8 @@ def forward(cfg, P, W, dt, imgs1, imgs_next, trans_matrices, num_agent, batch, m
         l_enc = L
     if taps is not None:
         taps["x0"] = x.clone()
-    for i in range(cfg.depth):
-        x = _block_fwd(x, P, W, "blocks.%d." % i, cfg.heads, n_frames, l_enc, dt, cfg.eps, save, train)
-        if taps is not None:
-            taps["enc_blk%d" % i] = x.clone()
-    y, mean_e, rstd_e = ops.layernorm_fwd(x, P["norm.weight"], P["norm.bias"], cfg.eps, dt, want_stats=train)
+    x, y, mean_e, rstd_e = _blocks_fwd(x, P, W, "blocks.%d.", cfg.depth, "norm", cfg.heads, n_frames, l_enc, dt, cfg.eps, save, train,
+                                       taps, "enc_blk%d")
     if taps is not None:
         taps["enc_norm"] = y.clone()
     comp_rows = None if cfg.encode_partial else src_row
@@ -428,11 +458,8 @@ def forward(cfg, P, W, dt, imgs1, imgs_next, trans_matrices, num_agent, batch, m
             taps["dec_val"] = val.clone()
     if taps is not None:
         taps["dec_x0"] = xd.clone()
-    for i in range(cfg.ddepth):
-        xd = _block_fwd(xd, P, W, "decoder_blocks.%d." % i, cfg.dheads, ba, L, dt, cfg.eps, save, train)
-        if taps is not None:
-            taps["dec_blk%d" % i] = xd.clone()
-    yd, mean_d, rstd_d = ops.layernorm_fwd(xd, P["decoder_norm.weight"], P["decoder_norm.bias"], cfg.eps, dt, want_stats=train)
+    xd, yd, mean_d, rstd_d = _blocks_fwd(xd, P, W, "decoder_blocks.%d.", cfg.ddepth, "decoder_norm", cfg.dheads, ba, L, dt, cfg.eps, save,
+                                         train, taps, "dec_blk%d")
     if taps is not None:
         taps["dec_norm"] = yd.clone()
     _, logits, _ = ops.gemm(yd, _heads(P, W, cfg, dt), bias=_heads_bias(P, W, cfg), want_lp=False, want_f32=True)

@@ -17,7 +17,7 @@ import torch
 
 from . import ops
 from ._lib import ACT_DRELU, ACT_RELU, BF16
-from .engine import _block_bwd, _block_fwd, _lin, _ln_bwd, _patch_weight, _put, _wg
+from .engine import _block_bwd, _blocks_fwd, _lin, _ln_bwd, _patch_weight, _put, _wg
 
 BN_EPS, BN_MOMENTUM = 1e-5, 0.1
 _ROWS = {}
@@ -160,9 +160,7 @@ def forward(cfg, P, W, dt, imgs1, imgs_next, teacher, trans_matrices, num_agent,
     a_pe = ops.patchify(imgs1, imgs_next if T > 1 else None, T, p, dt, channels_last_order=channels_last)
     _, x, _ = ops.gemm(a_pe, _patch_weight(P, W, cfg, dt, channels_last), bias=P["patch_embed.proj.bias"], res=P["pos_embed"][0, 1:], res_mod=L,
                        want_lp=False, want_f32=True)
-    for i in range(cfg.depth):
-        x = _block_fwd(x, P, W, "blocks.%d." % i, cfg.heads, n_frames, L, dt, cfg.eps, save, train)
-    y, mean_e, rstd_e = ops.layernorm_fwd(x, P["norm.weight"], P["norm.bias"], cfg.eps, dt, want_stats=train)
+    x, y, mean_e, rstd_e = _blocks_fwd(x, P, W, "blocks.%d.", cfg.depth, "norm", cfg.heads, n_frames, L, dt, cfg.eps, save, train)
     latent_lp, _, _ = ops.gemm(y, _lin(P, W, "compressor.0", dt), m=n_frames * keep, bias=P["compressor.0.bias"], act=ACT_RELU, a_rows=src_row)
 
     # ---- forward_fusion (:497-551): decompress, embed, un-mask (+ temporal embedding), warp + sum + threshold ---------------
@@ -183,9 +181,7 @@ def forward(cfg, P, W, dt, imgs1, imgs_next, teacher, trans_matrices, num_agent,
     xd = xd.reshape(ba * L, Dd)
 
     # ---- forward_decoder (:585-605) -----------------------------------------------------------------------------------
-    for i in range(cfg.ddepth):
-        xd = _block_fwd(xd, P, W, "decoder_blocks.%d." % i, cfg.dheads, ba, L, dt, cfg.eps, save, train)
-    yd, mean_d, rstd_d = ops.layernorm_fwd(xd, P["decoder_norm.weight"], P["decoder_norm.bias"], cfg.eps, dt, want_stats=train)
+    xd, yd, mean_d, rstd_d = _blocks_fwd(xd, P, W, "decoder_blocks.%d.", cfg.ddepth, "decoder_norm", cfg.dheads, ba, L, dt, cfg.eps, save, train)
     if taps is not None:
         taps["dec_norm"] = yd.clone()
     hs_free, hs_occ = ([] if train else None), ([] if train else None)

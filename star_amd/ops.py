@@ -227,6 +227,32 @@ def gemm_wgrad(dy, x, x_rows=None, want_bias=True, want_weight=True, dw=None, db
     return dw, db
 
 
+def gemm_res_ln_supported(n, k, dt):
+    return bool(L.lib().star_gemm_res_ln_supported(n, k, dt))
+
+
+def gemm_res_ln(a, w, bias, res, gamma, beta, eps, want_stats=True, out=None):
+    """x_out = res + a @ w^T + bias (float32) and h = LayerNorm(x_out) * gamma + beta (bf16) in one kernel (star_gemm_res_ln).
+    a [M, K], w [N, K] bf16; res float32 [M, N].  Returns (x_out, h, mean, rstd); `out` may be res."""
+    _cuda(a, w, res, gamma, beta)
+    m, k = a.shape
+    n = w.shape[0]
+    dt = L.dt_of(a)
+    assert a.is_contiguous() and w.is_contiguous() and res.is_contiguous() and w.shape[1] == k and w.dtype == a.dtype
+    assert res.shape == (m, n) and res.dtype == torch.float32 and bias.dtype == torch.float32 and bias.numel() == n
+    assert gamma.dtype == torch.float32 and beta.dtype == torch.float32 and gamma.numel() == n and beta.numel() == n
+    assert gamma.is_contiguous() and beta.is_contiguous() and bias.is_contiguous()
+    if out is None:
+        out = torch.empty_like(res)
+    h = torch.empty(m, n, dtype=a.dtype, device=a.device)
+    mean = torch.empty(m, dtype=torch.float32, device=a.device) if want_stats else None
+    rstd = torch.empty(m, dtype=torch.float32, device=a.device) if want_stats else None
+    with _timed("gemm_res_ln", 2.0 * m * n * k, float(m * k * 2 + n * k * 2 + m * n * (4 + 4 + 2))):
+        L.check(L.lib().star_gemm_res_ln(p(a), p(w), p(bias), p(res), p(out), p(gamma), p(beta), float(eps), p(h), p(mean), p(rstd),
+                                         m, n, k, dt, L.stream()))
+    return out, h, mean, rstd
+
+
 def mlp_supported(d, hid, dt):
     return bool(L.lib().star_mlp_fwd_supported(d, hid, dt))
 

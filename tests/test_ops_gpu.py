@@ -651,3 +651,48 @@ def test_layernorm_deferred_folds_in_one_launch_are_bit_identical():
     ops.ln_fold_batch(tab, n, max_d)
     for (ws, dg2, db2, m, d), (dg1, db1) in zip(jobs, want):
         assert torch.equal(dg1, dg2) and torch.equal(db1, db2)
+
+
+@pytest.mark.parametrize("m,n,k", [(40960, 384, 384), (5120, 384, 1536), (1000, 384, 64), (777, 256, 256), (4096, 256, 1024), (1, 384, 384),
+                                   (193, 384, 32)])
+def test_gemm_res_ln_one_kernel_against_gemm_then_layernorm(m, n, k, monkeypatch):
+    """star_gemm_res_ln against star_gemm (+ residual) followed by star_layernorm_fwd, and both against float64.  The float32
+    residual-stream result must be bit-identical only up to the summation order of the MFMA chain (same products, the bias is
+    added first instead of last): compared at float32 rounding; the bf16 LayerNorm output at one bf16 ulp of a unit-scale value."""
+    g = torch.Generator().manual_seed(m + n + k)
+    a = torch.randn(m, k, generator=g).to(DEV).bfloat16()
+    w = (torch.randn(n, k, generator=g) * k ** -0.5).to(DEV).bfloat16()
+    bias = torch.randn(n, generator=g).to(DEV)
+    res = (torch.randn(m, n, generator=g) * 3 + 0.5).to(DEV)
+    gamma, beta = torch.randn(n, generator=g).to(DEV), torch.randn(n, generator=g).to(DEV)
+    assert ops.gemm_res_ln_supported(n, k, 0)
+    _, x_ref, _ = ops.gemm(a, w, bias=bias, res=res, want_lp=False, want_f32=True)
+    h_ref, mean_ref, rstd_ref = ops.layernorm_fwd(x_ref, gamma, beta, 1e-6, 0)
+    for geo in ("0", "1", "2", "3"):
+        monkeypatch.setenv("STAR_AMD_GEMM_LN_GEO", geo)
+        x, h, mean, rstd = ops.gemm_res_ln(a, w, bias, res, gamma, beta, 1e-6)
+        x64 = res.double() + a.double() @ w.double().t() + bias.double()
+        assert (x - x64).abs().max().item() < 2e-5 * max(1.0, x64.abs().max().item())
+        assert (x - x_ref).abs().max().item() < 1e-5 * max(1.0, x64.abs().max().item())
+        mu64 = x64.mean(1, keepdim=True)
+        rs64 = (x64.var(1, unbiased=False, keepdim=True) + 1e-6).rsqrt()
+        h64 = (x64 - mu64) * rs64 * gamma.double() + beta.double()
+        assert (mean - mu64[:, 0]).abs().max().item() < 1e-5
+        assert ((rstd - rs64[:, 0]).abs() / rs64[:, 0]).max().item() < 1e-5
+        tol = 2.0 ** -8 * (h64.abs() + 1.0)
+        assert ((h.double() - h64).abs() <= tol).all()
+        assert ((h.double() - h_ref.double()).abs() <= 2 * tol).all()      # each is within tol of the float64 value
+    # in place on the residual stream (inference form), no statistics
+    res2 = res.clone()
+    x2, h2, mean2, rstd2 = ops.gemm_res_ln(a, w, bias, res2, gamma, beta, 1e-6, want_stats=False, out=res2)
+    assert x2 is res2 and mean2 is None and torch.equal(x2, x) and torch.equal(h2, h)
+
+
+def test_gemm_res_ln_rejects_unsupported_shapes():
+    assert not ops.gemm_res_ln_supported(128, 384, 0) and not ops.gemm_res_ln_supported(384, 40, 0)
+    assert not ops.gemm_res_ln_supported(384, 384, 1)
+    a = torch.zeros(8, 384, device=DEV, dtype=torch.bfloat16)
+    w = torch.zeros(128, 384, device=DEV, dtype=torch.bfloat16)
+    with pytest.raises(RuntimeError, match="star_gemm_res_ln"):
+        ops.gemm_res_ln(a, w, torch.zeros(128, device=DEV), torch.zeros(8, 128, device=DEV), torch.ones(128, device=DEV),
+                        torch.zeros(128, device=DEV), 1e-6)

@@ -70,6 +70,29 @@ def wgrad_cases():
     return rows
 
 
+def gemm_ln_cases():
+    """residual Linear + the LayerNorm behind it: one kernel against the two launches."""
+    rows = []
+    g = torch.Generator().manual_seed(0)
+    for name, N, K in [("proj+res+ln", 384, 384), ("fc2+res+ln", 384, 1536), ("dec proj+ln", 256, 256), ("dec fc2+ln", 256, 1024)]:
+        a = torch.randn(M, K, generator=g).to(dev).bfloat16()
+        w = (torch.randn(N, K, generator=g) * K ** -0.5).to(dev).bfloat16()
+        bias = torch.randn(N, generator=g).to(dev)
+        res = torch.randn(M, N, generator=g).to(dev)
+        gam, bet = torch.ones(N, device=dev), torch.zeros(N, device=dev)
+        out = torch.empty(M, N, device=dev)
+
+        def two():
+            ops.gemm(a, w, bias=bias, res=res, want_lp=False, want_f32=True, out_f32=out)
+            ops.layernorm_fwd(out, gam, bet, 1e-6, 0)
+        us2 = timeit(two)
+        us1 = timeit(lambda: ops.gemm_res_ln(a, w, bias, res, gam, bet, 1e-6, out=out))
+        byt = M * K * 2 + M * N * 10
+        rows.append((name + " 2 launches", N, K, us2, 2.0 * M * N * K / us2 / 1e6, byt / us2 / 1e3))
+        rows.append((name + " fused", N, K, us1, 2.0 * M * N * K / us1 / 1e6, byt / us1 / 1e3))
+    return rows
+
+
 def mlp_cases():
     """block MLP forward: the one-kernel path against the two GEMM launches (training: with the gelu / gelu' stores)."""
     rows = []
@@ -167,6 +190,6 @@ def vq_cases():
 if __name__ == "__main__":
     which = sys.argv[1:] or ["gemm", "wgrad", "mlp", "attn", "ln", "voxel", "vq"]
     for w in which:
-        rows = dict(gemm=gemm_cases, wgrad=wgrad_cases, mlp=mlp_cases, attn=attn_cases, ln=ln_cases, voxel=voxel_cases, vq=vq_cases)[w]()
+        rows = dict(gemm=gemm_cases, gemm_ln=gemm_ln_cases, wgrad=wgrad_cases, mlp=mlp_cases, attn=attn_cases, ln=ln_cases, voxel=voxel_cases, vq=vq_cases)[w]()
         for name, a, b, us, tf, gbs in rows:
             print("%-26s %5d %5d  %8.1f us  %7.1f TFLOP/s  %7.1f GB/s(or Gexp/s)" % (name, a, b, us, tf, gbs))
