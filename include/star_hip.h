@@ -162,20 +162,6 @@ int star_gemm_res_ln(const void* A, const void* W, const float* bias, const floa
                      const float* beta, float eps, void* h, float* mean, float* rstd, int M, int N, int K, int dt,
                      void* stream);
 
-/* Backward twin: the input gradient of the Linear that reads a LayerNorm's output and that LayerNorm's backward, one launch.
- * Replaces autograd's backward of `fc1(norm2(x))` / `qkv(norm1(x))` down to the residual stream (timm 0.3.2 Block.forward; ctor
- * mae_base.py:279-281,308-310):  dy = A W^T (A [M, K] = gradient of the Linear's output, W [N, K] = its weight transposed, bf16;
- * dy stays on chip, float32), then exactly star_layernorm_bwd's results from dy: g_out / g_out_lp = g_in + dx (g_in required,
- * g_out may be g_in), dgamma / dbeta [N].  ws float32 [star_gemm_ln_bwd_ws(M, N)]; with dgamma == dbeta == NULL the
- * star_gemm_ln_bwd_rows(M) partial rows stay in ws for star_layernorm_fold_batch (StarLnFoldJob.nb = that row count).
- * Shapes as star_gemm_res_ln (bf16, N = 256 or 384, K % 32 == 0); others -> error. */
-int star_gemm_ln_bwd_supported(int N, int K, int dt);
-int star_gemm_ln_bwd_rows(int M);
-int64_t star_gemm_ln_bwd_ws(int M, int N);
-int star_gemm_ln_bwd(const void* A, const void* W, const float* x, const float* gamma, const float* mean, const float* rstd,
-                     const float* g_in, float* g_out, void* g_out_lp, float* dgamma, float* dbeta, float* ws, int M, int N,
-                     int K, int dt, void* stream);
-
 /* ---- K3': the block's MLP forward as one kernel ---------------------------------------------------------
  * Replaces timm 0.3.2 Mlp.forward plus the block's second residual add (Block.forward: x = x + mlp(norm2(x)); ctor
  * mae_base.py:279-281,308-310): xout[M, D] (float32) = xres + fc2(gelu(fc1(h))) with h [M, D], w1 [HID, D], w2 [D, HID] in bf16

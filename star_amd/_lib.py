@@ -52,10 +52,6 @@ _SIGS = {
     "star_attn_bwd": (C.c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "star_gemm_res_ln_supported": (C.c_int, [_I, _I, _I]),
     "star_gemm_res_ln": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, C.c_float, _P, _P, _P, _I, _I, _I, _I, _P]),
-    "star_gemm_ln_bwd_supported": (C.c_int, [_I, _I, _I]),
-    "star_gemm_ln_bwd_rows": (C.c_int, [_I]),
-    "star_gemm_ln_bwd_ws": (C.c_int64, [_I, _I]),
-    "star_gemm_ln_bwd": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "star_mlp_fwd_supported": (C.c_int, [_I, _I, _I]),
     "star_mlp_fwd": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "star_attn_bwd_ws_bytes": (C.c_int64, [_I, _I, _I, _I, _I]),

@@ -9,7 +9,6 @@
 
 int star_set_error(int code, const char* fmt, ...);
 int star_num_cus();   // compute units of the current device (cached)
-int star_ln_fold_launch(const float* ws, float* dgamma, float* dbeta, int nb, int D, hipStream_t s);   // layernorm.hip
 
 #define STAR_CHECK(cond, ...)                                  \
     do {                                                       \

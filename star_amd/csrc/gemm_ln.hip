@@ -27,9 +27,9 @@ __device__ __forceinline__ int gl_swz(int row) { return (0x78 >> (((row >> 2) & 
 // lanes write one contiguous 64-byte segment per 16-byte bf16 store, and two adjacent 16-byte pieces per float32 store pair
 __device__ __forceinline__ int gl_run_off(int lg, int a) { return (a >> 1) * 32 + lg * 8 + (a & 1) * 4; }
 
-// The main loop both kernels share: acc[a][b] += A-tile x W-panel over all of K.  Waves WM x WN; a wave owns RB 16-row blocks and
-// CB 16-column blocks (CB * 16 adjacent columns).  `acc` comes in initialised (bias or zero).  Leaves the ring possibly still being
-// read by slower waves: callers put a barrier before they reuse it.
+// The main loop: acc[a][b] += A-tile x W-panel over all of K.  Waves WM x WN; a wave owns RB 16-row blocks and
+// CB 16-column blocks (CB * 16 adjacent columns).  `acc` comes in initialised (the bias).  Leaves the ring possibly still being
+// read by slower waves: a caller that reuses it puts a barrier first.
 template <int NST, int WM, int WN, int RB, int CB>
 __device__ __forceinline__ void gl_mainloop(const bf16_t* __restrict__ A, const bf16_t* __restrict__ W, int M, int K, int m_blk,
                                             unsigned char* smem, gl_f32x4_t (&acc)[CB][RB]) {
@@ -281,224 +281,3 @@ extern "C" int star_gemm_res_ln(const void* A, const void* W, const float* bias,
     return 0;
 }
 
-// ------------------------------------------------------------------------------------------------------------------------
-// Backward twin: the input gradient of the Linear that reads a LayerNorm's output, and that LayerNorm's backward, one launch.
-//   dy[m, :]    = A[m, :] W^T                                   (A = dL/d(Linear output) [M, K], W = weight^T [N, K]; stays on chip)
-//   g_out[m, :] = g_in[m, :] + rstd (dy gamma - mean(dy gamma) - xhat mean(dy gamma xhat)),  xhat = (x - mean) rstd
-//   ws[tile]    = column sums over the tile's rows of dy xhat and dy  (dgamma / dbeta partial rows, folded like ln_bwd_kernel's)
-// Replaces autograd's backward of `fc1(norm2(x))` / `qkv(norm1(x))` down to the residual stream (timm Block.forward; ctor
-// mae_base.py:279-281,308-310).  dy never reaches HBM (the separate pair writes it as bf16 and reads it back: 63 MB per
-// LayerNorm at M = 40 960, D = 384) and is used at float32.
-// Waves 2 x 4, each RB = 4 row blocks x CB column blocks (96 columns at N = 384): 8 waves = 2 per SIMD, so the epilogue has 256
-// registers: the accumulators (dy, then dy gamma), the column partials and two row groups of x / g_in in flight.  x is read
-// twice (statistics pass, output pass); the second read of a tile's 196 KB comes from L2 / MALL.
-// v of the lane n places below in the same 16-lane row (0 where there is none)
-template <int NSH> __device__ __forceinline__ float gl_row_shr(float v) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x110 + NSH, 0xf, 0xf, true));
-}
-// LDS store the compiler does not see (a visible access to the LDS-DMA ring makes it drain vmcnt first -- the prefetched rows)
-__device__ __forceinline__ void gl_lds_w4(unsigned addr, gl_f32x4_t v) { asm volatile("ds_write_b128 %0, %1" ::"v"(addr), "v"(v) : "memory"); }
-
-template <int NST, int WM, int WN, int RB, int CB>
-__global__ __launch_bounds__(WM * WN * 64) __attribute__((amdgpu_waves_per_eu(2)))
-void gemm_ln_bwd_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ W, const float* __restrict__ x,
-                        const float* __restrict__ gamma, const float* __restrict__ mean, const float* __restrict__ rstd,
-                        const float* g_in, float* g_out, bf16_t* __restrict__ g_lp, float* __restrict__ ws, int M, int K) {
-    constexpr int NW = WM * WN, BM = WM * RB * 16, CW = CB * 16, N = WN * CW, STAGE = (BM + N) * 64, E = CB * 4;
-    static_assert(CB % 2 == 0, "bf16 stores take column-block pairs");
-    static_assert(NST * STAGE >= RB * WM * 4 * 2 * N * 4, "the column-partial image reuses the ring");
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    float* s_r1 = reinterpret_cast<float*>(smem + NST * STAGE);   // [BM][WN] sum(dy gamma) per column wave
-    float* s_r2 = s_r1 + BM * WN;                                   // [BM][WN] sum(dy gamma xhat)
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave % WM, wn = wave / WM;
-    const int lr = lane & 15, lg = lane >> 4;
-    const int m_blk = blockIdx.x * BM;
-    int coff[CB];
-#pragma unroll
-    for (int a = 0; a < CB; ++a) coff[a] = wn * CW + gl_run_off(lg, a);
-    gl_f32x4_t acc[CB][RB];
-#pragma unroll
-    for (int a = 0; a < CB; ++a)
-#pragma unroll
-        for (int b = 0; b < RB; ++b) acc[a][b] = (gl_f32x4_t){0.f, 0.f, 0.f, 0.f};
-    gl_mainloop<NST, WM, WN, RB, CB>(A, W, M, K, m_blk, smem, acc);
-
-    // ---- epilogue.  Lane (lr, lg) owns rows wm*RB*16 + b*16 + lr and CB 4-column runs of its wave's columns.  Rows past M have
-    // dy = 0 (their A rows were zero-filled): they add nothing to the column partials; their reads are clamped, their stores skipped.
-    const int row0 = wm * (RB * 16) + lr;
-    // 32-bit element offsets from the (uniform) table bases: one address register per access instead of a 64-bit pair per row.
-    // Both passes walk the tile in STEPS of one row group x one pair of column blocks (8 values per lane and table), reading
-    // AHEAD steps in front: the whole-group granularity (24 values per table, double-buffered) does not fit beside 96 accumulators.
-    constexpr int SPG = CB / 2, T = RB * SPG;
-    unsigned ro[RB];
-    float mu[RB], rs[RB];
-#pragma unroll
-    for (int b = 0; b < RB; ++b) {
-        const int mc = min(m_blk + row0 + b * 16, M - 1);
-        ro[b] = (unsigned)mc * (unsigned)N;
-        mu[b] = mean[mc];
-        rs[b] = rstd[mc];
-    }
-    auto ldpair = [&](const float* base, int st, gl_f32x4_t (&dst)[2]) {
-        const int b = st / SPG, pr = st % SPG;
-        dst[0] = *reinterpret_cast<const gl_f32x4_t*>(base + (ro[b] + (unsigned)coff[2 * pr]));
-        dst[1] = *reinterpret_cast<const gl_f32x4_t*>(base + (ro[b] + (unsigned)coff[2 * pr + 1]));
-    };
-    // pass A: dy -> dy gamma in the accumulators, the lane's share of the two row sums, and the column partials: the products of one
-    // row group are summed over four lanes of the 16 that hold the group's rows (two DPP steps) and every fourth lane writes its
-    // sums into the column-partial image (ring space: all waves are past the main loop) -- nothing is carried in registers.
-    __syncthreads();
-    float* s_col = reinterpret_cast<float*>(smem);   // [RB * WM * 4][2][N] rows of column partials
-    float s1[RB], s2[RB];
-    {
-        constexpr int AHEAD = 4, NBUF = AHEAD + 1;
-        gl_f32x4_t gm[CB], px[NBUF][2];
-#pragma unroll
-        for (int a = 0; a < CB; ++a) gm[a] = *reinterpret_cast<const gl_f32x4_t*>(gamma + coff[a]);
-#pragma unroll
-        for (int st = 0; st < AHEAD && st < T; ++st) ldpair(x, st, px[st % NBUF]);
-#pragma unroll
-        for (int st = 0; st < T; ++st) {
-            const int b = st / SPG, pr = st % SPG;
-            if (pr == 0) s1[b] = s2[b] = 0.f;
-            const unsigned colrow = (unsigned)(((b * WM + wm) * 4 + (lr >> 2)) * 2) * N * 4;
-#pragma unroll
-            for (int hh = 0; hh < 2; ++hh) {
-                const int a = 2 * pr + hh;
-                gl_f32x4_t t1, t0;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const float xh = (px[st % NBUF][hh][j] - mu[b]) * rs[b];
-                    const float dy = acc[a][b][j];
-                    t1[j] = dy * xh;
-                    t0[j] = dy;
-                    const float dg = dy * gm[a][j];
-                    acc[a][b][j] = dg;
-                    s1[b] += dg;
-                    s2[b] += dg * xh;
-                }
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    t1[j] += gl_row_shr<1>(t1[j]);
-                    t0[j] += gl_row_shr<1>(t0[j]);
-                    t1[j] += gl_row_shr<2>(t1[j]);
-                    t0[j] += gl_row_shr<2>(t0[j]);
-                }
-                if ((lr & 3) == 3) {
-                    gl_lds_w4(colrow + coff[a] * 4, t1);
-                    gl_lds_w4(colrow + N * 4 + coff[a] * 4, t0);
-                }
-            }
-            if (st + AHEAD < T) ldpair(x, st + AHEAD, px[(st + AHEAD) % NBUF]);
-            if (pr == SPG - 1) {
-                s1[b] += __shfl_xor(s1[b], 16, 64);
-                s1[b] += __shfl_xor(s1[b], 32, 64);
-                s2[b] += __shfl_xor(s2[b], 16, 64);
-                s2[b] += __shfl_xor(s2[b], 32, 64);
-            }
-        }
-    }
-    if (lg == 0) {
-#pragma unroll
-        for (int b = 0; b < RB; ++b) {
-            s_r1[(row0 + b * 16) * WN + wn] = s1[b];
-            s_r2[(row0 + b * 16) * WN + wn] = s2[b];
-        }
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the hand-issued column-partial writes
-    __syncthreads();   // row sums and column partials are complete
-    {
-        // pass B: the output rows.  g_out may alias g_in (same elements, read before written by the same lane).
-        constexpr int AHEAD = 3, NBUF = AHEAD + 1;
-        gl_f32x4_t px[NBUF][2], pgi[NBUF][2];
-#pragma unroll
-        for (int st = 0; st < AHEAD && st < T; ++st) {
-            ldpair(x, st, px[st % NBUF]);
-            ldpair(g_in, st, pgi[st % NBUF]);
-        }
-        float m1 = 0.f, m2 = 0.f;
-#pragma unroll
-        for (int st = 0; st < T; ++st) {
-            const int b = st / SPG, pr = st % SPG;
-            if (pr == 0) {
-                m1 = m2 = 0.f;
-#pragma unroll
-                for (int w = 0; w < WN; ++w) {
-                    m1 += s_r1[(row0 + b * 16) * WN + w];
-                    m2 += s_r2[(row0 + b * 16) * WN + w];
-                }
-                m1 /= (float)N;
-                m2 /= (float)N;
-            }
-            gl_f32x4_t o[2];
-#pragma unroll
-            for (int hh = 0; hh < 2; ++hh)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const float xh = (px[st % NBUF][hh][j] - mu[b]) * rs[b];
-                    o[hh][j] = rs[b] * (acc[2 * pr + hh][b][j] - m1 - xh * m2) + pgi[st % NBUF][hh][j];
-                }
-            if (st + AHEAD < T) {
-                ldpair(x, st + AHEAD, px[(st + AHEAD) % NBUF]);
-                ldpair(g_in, st + AHEAD, pgi[(st + AHEAD) % NBUF]);
-            }
-            if (m_blk + row0 + b * 16 < M) {      // (ro[b] is this row's offset: the clamp only changed rows past M)
-                if (g_out) {
-                    *reinterpret_cast<gl_f32x4_t*>(g_out + (ro[b] + (unsigned)coff[2 * pr])) = o[0];
-                    *reinterpret_cast<gl_f32x4_t*>(g_out + (ro[b] + (unsigned)coff[2 * pr + 1])) = o[1];
-                }
-                if (g_lp)
-                    *reinterpret_cast<uint4*>(g_lp + (ro[b] + (unsigned)coff[2 * pr])) =
-                        make_uint4(pack_bf16(o[0][0], o[0][1]), pack_bf16(o[0][2], o[0][3]), pack_bf16(o[1][0], o[1][1]), pack_bf16(o[1][2], o[1][3]));
-            }
-        }
-    }
-    for (int c = tid; c < 2 * N; c += NW * 64) {
-        const int which = c / N, col = c - which * N;
-        float a = 0.f;
-#pragma unroll 8
-        for (int r = 0; r < RB * WM * 4; ++r) a += s_col[(size_t)(r * 2 + which) * N + col];
-        ws[(size_t)blockIdx.x * 2 * N + c] = a;
-    }
-}
-
-template <int NST, int WM, int WN, int RB, int CB>
-static int launch_ln_bwd(const void* A, const void* W, const float* x, const float* gamma, const float* mean, const float* rstd,
-                         const float* g_in, float* g_out, void* g_lp, float* ws, int M, int K, hipStream_t s) {
-    constexpr int BM = WM * RB * 16, N = WN * CB * 16;
-    const size_t lds = (size_t)NST * (BM + N) * 64 + (size_t)2 * BM * WN * sizeof(float);
-    static bool attr_done = false;
-    if (!attr_done && lds > 48 * 1024) {
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_ln_bwd_kernel<NST, WM, WN, RB, CB>),
-                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return star_set_error(-2, "star_gemm_ln_bwd: LDS attribute: %s", hipGetErrorString(e));
-        attr_done = true;
-    }
-    hipLaunchKernelGGL((gemm_ln_bwd_kernel<NST, WM, WN, RB, CB>), dim3(cdiv(M, BM)), dim3(WM * WN * 64), lds, s, (const bf16_t*)A,
-                       (const bf16_t*)W, x, gamma, mean, rstd, g_in, g_out, (bf16_t*)g_lp, ws, M, K);
-    return 0;
-}
-
-#define GLB_BM 128   // rows per tile of the backward kernel = rows per dgamma / dbeta partial row
-extern "C" int star_gemm_ln_bwd_supported(int N, int K, int dt) { return star_gemm_res_ln_supported(N, K, dt); }
-extern "C" int star_gemm_ln_bwd_rows(int M) { return cdiv(M, GLB_BM); }
-extern "C" int64_t star_gemm_ln_bwd_ws(int M, int N) { return (int64_t)cdiv(M, GLB_BM) * 2 * N; }
-
-extern "C" int star_gemm_ln_bwd(const void* A, const void* W, const float* x, const float* gamma, const float* mean,
-                                const float* rstd, const float* g_in, float* g_out, void* g_lp, float* dgamma, float* dbeta,
-                                float* ws, int M, int N, int K, int dt, void* stream) {
-    STAR_CHECK(A && W && x && gamma && mean && rstd && g_in && ws, "star_gemm_ln_bwd: null pointer");
-    STAR_CHECK(g_out || g_lp, "star_gemm_ln_bwd: no output requested");
-    STAR_CHECK(star_gemm_ln_bwd_supported(N, K, dt), "star_gemm_ln_bwd: no kernel for N=%d K=%d dt=%d (bf16, N = 256 or 384, K %% 32 == 0)", N, K, dt);
-    STAR_CHECK(M > 0 && (long long)M * K * 2 < 0x7fffffffLL && (long long)M * N < 0x7fffffffLL,
-               "star_gemm_ln_bwd: M=%d K=%d: M > 0, the A operand below 2 GiB and M * N below 2^31", M, K);
-    hipStream_t s = (hipStream_t)stream;
-    const int rc = N == 384 ? launch_ln_bwd<3, 2, 4, 4, 6>(A, W, x, gamma, mean, rstd, g_in, g_out, g_lp, ws, M, K, s)
-                            : launch_ln_bwd<3, 2, 4, 4, 4>(A, W, x, gamma, mean, rstd, g_in, g_out, g_lp, ws, M, K, s);
-    if (rc) return rc;
-    STAR_LAUNCH_CHECK("star_gemm_ln_bwd");
-    if (dgamma == nullptr && dbeta == nullptr) return 0;   // deferred: the partial rows stay in ws for star_layernorm_fold_batch
-    return star_ln_fold_launch(ws, dgamma, dbeta, cdiv(M, GLB_BM), N, s);
-}

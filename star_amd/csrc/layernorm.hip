@@ -236,13 +236,6 @@ static int ln_bwd_launch(const void* dy, const float* x, const float* gamma, con
     return 0;
 }
 
-// fold of `nb` partial rows left in ws by a LayerNorm backward (also the one inside star_gemm_ln_bwd, gemm_ln.hip)
-int star_ln_fold_launch(const float* ws, float* dgamma, float* dbeta, int nb, int D, hipStream_t s) {
-    hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3(cdiv(2 * D, 16)), dim3(1024), 0, s, ws, dgamma, dbeta, nb, D);
-    STAR_LAUNCH_CHECK("star_layernorm_bwd(reduce)");
-    return 0;
-}
-
 // The folds of MANY LayerNorm backward calls in one launch (grid.y = job): a training step has 22 LayerNorms whose dgamma / dbeta
 // nothing in the backward chain waits for; each fold is a 5 us launch on the critical path when issued beside its LayerNorm.
 __global__ __launch_bounds__(1024) void ln_fold_batch_kernel(const StarLnFoldJob* __restrict__ jobs) {

@@ -162,13 +162,11 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, g_in=None, want_lp=True, g_out=None,
 
 
 def ln_fold_table(jobs, device):
-    """Device job table for ln_fold_batch: jobs = [(ws, dgamma, dbeta, M, D[, partial rows]), ...] -> (table tensor, njobs, max D)."""
+    """Device job table for ln_fold_batch: jobs = [(ws, dgamma, dbeta, M, D), ...] -> (table tensor, njobs, max D)."""
     rec = np.zeros(len(jobs), dtype=np.dtype([("ws", "<u8"), ("dg", "<u8"), ("db", "<u8"), ("nb", "<i4"), ("D", "<i4")]))
-    for i, job in enumerate(jobs):
-        ws, dg, db, m, d = job[:5]
-        nb = job[5] if len(job) > 5 else L.lib().star_layernorm_fold_rows(m)   # partial rows (6th entry: another kernel left them)
-        assert dg.is_contiguous() and db.is_contiguous() and dg.numel() == d and db.numel() == d and ws.numel() >= nb * 2 * d
-        rec[i] = (ws.data_ptr(), dg.data_ptr(), db.data_ptr(), nb, d)
+    for i, (ws, dg, db, m, d) in enumerate(jobs):
+        assert dg.is_contiguous() and db.is_contiguous() and dg.numel() == d and db.numel() == d
+        rec[i] = (ws.data_ptr(), dg.data_ptr(), db.data_ptr(), L.lib().star_layernorm_fold_rows(m), d)
     tab = torch.from_numpy(rec.view(np.uint8).copy()).to(device)
     return tab, len(jobs), max(j[4] for j in jobs)
 
@@ -253,39 +251,6 @@ def gemm_res_ln(a, w, bias, res, gamma, beta, eps, want_stats=True, out=None):
         L.check(L.lib().star_gemm_res_ln(p(a), p(w), p(bias), p(res), p(out), p(gamma), p(beta), float(eps), p(h), p(mean), p(rstd),
                                          m, n, k, dt, L.stream()))
     return out, h, mean, rstd
-
-
-def gemm_ln_bwd_supported(n, k, dt):
-    return bool(L.lib().star_gemm_ln_bwd_supported(n, k, dt))
-
-
-def gemm_ln_bwd(a, w, x, gamma, mean, rstd, g_in, want_lp=True, g_out=None, dgamma=None, dbeta=None, defer_ws=None):
-    """Input gradient of the Linear behind a LayerNorm and that LayerNorm's backward in one kernel (star_gemm_ln_bwd):
-    dy = a @ w^T (a [M, K] = gradient of the Linear's output, w [N, K] = its weight transposed, bf16), then as layernorm_bwd.
-    -> (g_out float32 [M, N] = g_in + dx, g_lp bf16 copy or None, dgamma, dbeta).  defer_ws: caller-kept workspace; the partial
-    dgamma / dbeta rows (star_gemm_ln_bwd_rows(M) of them) stay in it for ln_fold_batch and dgamma / dbeta are not written."""
-    _cuda(a, w, x, gamma, mean, rstd, g_in)
-    m, k = a.shape
-    n = w.shape[0]
-    dt = L.dt_of(a)
-    assert a.is_contiguous() and w.is_contiguous() and x.is_contiguous() and g_in.is_contiguous() and w.shape[1] == k and w.dtype == a.dtype
-    assert x.shape == (m, n) and x.dtype == torch.float32 and g_in.shape == (m, n) and g_in.dtype == torch.float32
-    assert gamma.numel() == n and gamma.dtype == torch.float32 and mean.numel() == m and rstd.numel() == m
-    if g_out is None:
-        g_out = torch.empty(m, n, dtype=torch.float32, device=a.device)
-    g_lp = torch.empty(m, n, dtype=a.dtype, device=a.device) if want_lp else None
-    if dgamma is None:
-        dgamma = torch.empty(n, dtype=torch.float32, device=a.device)
-    if dbeta is None:
-        dbeta = torch.empty(n, dtype=torch.float32, device=a.device)
-    defer = defer_ws is not None
-    need = L.lib().star_gemm_ln_bwd_ws(m, n)
-    ws = defer_ws if defer else torch.empty(need, dtype=torch.float32, device=a.device)
-    assert ws.numel() >= need and ws.dtype == torch.float32
-    with _timed("gemm_ln_bwd", 2.0 * m * n * k, float(m * k * 2 + n * k * 2 + m * n * (4 + 4 + 4 + 2))):
-        L.check(L.lib().star_gemm_ln_bwd(p(a), p(w), p(x), p(gamma), p(mean), p(rstd), p(g_in), p(g_out), p(g_lp),
-                                         None if defer else p(dgamma), None if defer else p(dbeta), p(ws), m, n, k, dt, L.stream()))
-    return g_out, g_lp, dgamma, dbeta
 
 
 def mlp_supported(d, hid, dt):

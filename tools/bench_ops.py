@@ -93,30 +93,6 @@ def gemm_ln_cases():
     return rows
 
 
-def gemm_lnb_cases():
-    """input gradient of the Linear behind a LayerNorm + that LayerNorm's backward: one kernel against the two launches."""
-    rows = []
-    g = torch.Generator().manual_seed(0)
-    for name, N, K in [("dfc1+ln2 bwd", 384, 1536), ("dqkv+ln1 bwd", 384, 1152), ("dec dfc1+ln", 256, 1024), ("dec dqkv+ln", 256, 768)]:
-        a = torch.randn(M, K, generator=g).to(dev).bfloat16()
-        w = (torch.randn(N, K, generator=g) * K ** -0.5).to(dev).bfloat16()
-        x = torch.randn(M, N, generator=g).to(dev)
-        gam = torch.ones(N, device=dev)
-        _, mean, rstd = ops.layernorm_fwd(x, gam, torch.zeros(N, device=dev), 1e-6, 0)
-        gin = torch.randn(M, N, generator=g).to(dev)
-        gout = torch.empty(M, N, device=dev)
-
-        def two():
-            dy, _, _ = ops.gemm(a, w)
-            ops.layernorm_bwd(dy, x, gam, mean, rstd, g_in=gin, g_out=gout)
-        us2 = timeit(two)
-        us1 = timeit(lambda: ops.gemm_ln_bwd(a, w, x, gam, mean, rstd, gin, g_out=gout))
-        byt = M * K * 2 + M * N * 14
-        rows.append((name + " 2 launches", N, K, us2, 2.0 * M * N * K / us2 / 1e6, byt / us2 / 1e3))
-        rows.append((name + " fused", N, K, us1, 2.0 * M * N * K / us1 / 1e6, byt / us1 / 1e3))
-    return rows
-
-
 def mlp_cases():
     """block MLP forward: the one-kernel path against the two GEMM launches (training: with the gelu / gelu' stores)."""
     rows = []
@@ -214,6 +190,6 @@ def vq_cases():
 if __name__ == "__main__":
     which = sys.argv[1:] or ["gemm", "wgrad", "mlp", "attn", "ln", "voxel", "vq"]
     for w in which:
-        rows = dict(gemm=gemm_cases, gemm_ln=gemm_ln_cases, gemm_lnb=gemm_lnb_cases, wgrad=wgrad_cases, mlp=mlp_cases, attn=attn_cases, ln=ln_cases, voxel=voxel_cases, vq=vq_cases)[w]()
+        rows = dict(gemm=gemm_cases, gemm_ln=gemm_ln_cases, wgrad=wgrad_cases, mlp=mlp_cases, attn=attn_cases, ln=ln_cases, voxel=voxel_cases, vq=vq_cases)[w]()
         for name, a, b, us, tf, gbs in rows:
             print("%-26s %5d %5d  %8.1f us  %7.1f TFLOP/s  %7.1f GB/s(or Gexp/s)" % (name, a, b, us, tf, gbs))
