@@ -156,8 +156,10 @@ int star_gemm_wgrad(const void* dY, const void* X, const int32_t* x_rows, float*
  * mae_base.py:282,312):  x_out[M, N] (float32) = res + A W^T + bias;  h[M, N] (bf16) = LayerNorm_eps(x_out) * gamma + beta;
  * mean / rstd [M] optional.  A [M, K], W [N, K] bf16; N = 256 or 384 (a tile spans whole rows), K % 32 == 0.  x_out may be res.
  * star_gemm_res_ln_supported(N, K, dt) != 0 tells whether a kernel exists; other shapes -> error (callers launch star_gemm and
- * star_layernorm_fwd instead). */
+ * star_layernorm_fwd instead).  A tile spans whole rows, so small M leaves CUs idle: star_gemm_res_ln_prefers says whether the one
+ * launch is expected to be the faster path at this M (measured on MI355X). */
 int star_gemm_res_ln_supported(int N, int K, int dt);
+int star_gemm_res_ln_prefers(int M, int N, int K, int dt);   /* supported AND expected to beat the two launches at this M */
 int star_gemm_res_ln(const void* A, const void* W, const float* bias, const float* res, float* x_out, const float* gamma,
                      const float* beta, float eps, void* h, float* mean, float* rstd, int M, int N, int K, int dt,
                      void* stream);

@@ -51,6 +51,7 @@ _SIGS = {
     "star_attn_fwd": (C.c_int, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "star_attn_bwd": (C.c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "star_gemm_res_ln_supported": (C.c_int, [_I, _I, _I]),
+    "star_gemm_res_ln_prefers": (C.c_int, [_I, _I, _I, _I]),
     "star_gemm_res_ln": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, C.c_float, _P, _P, _P, _I, _I, _I, _I, _P]),
     "star_mlp_fwd_supported": (C.c_int, [_I, _I, _I]),
     "star_mlp_fwd": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),

@@ -256,6 +256,24 @@ extern "C" int star_gemm_res_ln_supported(int N, int K, int dt) {
     return dt == STAR_BF16 && (N == 256 || N == 384) && K >= 32 && K % 32 == 0;
 }
 
+// Geometry by shape, from measurements on MI355X (tools/bench_ops.py gemm_ln at M = 5120 .. 40 960).  A tile
+// spans whole rows, so M alone sets the number of workgroups: -1 = the two-launch path is faster (too few tiles for the chip).
+//   N = 384: 192-row tiles (12 waves) once they cover 3/4 of the CUs; below that 96-row tiles (6 waves, two per CU) while K <= 512
+//            (they re-read the W panel twice as often: at K = 1536 they lose to star_gemm + star_layernorm_fwd);
+//   N = 256: 128-row tiles (8 waves) from half the CUs up, 64-row tiles (4 waves) below.
+static int res_ln_geometry(int M, int N, int K) {
+    const int cus = star_num_cus();
+    if (N == 384) {
+        if (cdiv(M, 192) * 4 >= cus * 3) return 0;
+        return K <= 512 ? 1 : -1;
+    }
+    return cdiv(M, 128) * 2 >= cus ? 0 : 1;
+}
+
+extern "C" int star_gemm_res_ln_prefers(int M, int N, int K, int dt) {
+    return star_gemm_res_ln_supported(N, K, dt) && M > 0 && res_ln_geometry(M, N, K) >= 0;
+}
+
 extern "C" int star_gemm_res_ln(const void* A, const void* W, const float* bias, const float* res, float* x_out,
                                 const float* gamma, const float* beta, float eps, void* h, float* mean, float* rstd, int M,
                                 int N, int K, int dt, void* stream) {
@@ -264,7 +282,8 @@ extern "C" int star_gemm_res_ln(const void* A, const void* W, const float* bias,
     STAR_CHECK(M >= 0 && (long long)M * K * 2 < 0x7fffffffLL, "star_gemm_res_ln: M=%d K=%d: the A operand must stay below 2 GiB", M, K);
     if (M == 0) return 0;
     const char* env = getenv("STAR_AMD_GEMM_LN_GEO");   // read per call (tests walk the geometries in one process)
-    const int geo = env ? atoi(env) : 0;
+    int geo = env ? atoi(env) : res_ln_geometry(M, N, K);
+    if (geo < 0) geo = N == 384 ? 1 : 0;                 // called although the two-launch path is faster: still correct
     hipStream_t s = (hipStream_t)stream;
     int rc;
     if (N == 384) {

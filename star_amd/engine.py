@@ -154,7 +154,7 @@ def _block_fwd(x, P, W, pre, heads, nb, l, dt, eps, save, train, ln1=None, nxt=N
     ln = (h, mean, rstd) of that LayerNorm (from the fc2 kernel where star_gemm_res_ln covers the shape), else x_out alone."""
     d = x.shape[1]
     hd = d // heads
-    fuse_ln = _GEMM_LN and ops.gemm_res_ln_supported(d, d, dt)
+    fuse_ln = _GEMM_LN and ops.gemm_res_ln_prefers(x.shape[0], d, d, dt)
     h1, mean1, rstd1 = ln1 if ln1 is not None else ops.layernorm_fwd(x, P[pre + "norm1.weight"], P[pre + "norm1.bias"], eps, dt, want_stats=train)
     qkv, _, _ = ops.gemm(h1, _lin(P, W, pre + "attn.qkv", dt), bias=P[pre + "attn.qkv.bias"])
     a, lse = ops.attn_fwd(qkv, nb, l, heads, hd)
@@ -172,7 +172,7 @@ def _block_fwd(x, P, W, pre, heads, nb, l, dt, eps, save, train, ln1=None, nxt=N
         x_out, v, u = ops.mlp_fwd(h2, w1, P[pre + "mlp.fc1.bias"], w2, P[pre + "mlp.fc2.bias"], x_mid, train, out=None if train else x_mid)
     else:
         v, _, u = ops.gemm(h2, w1, bias=P[pre + "mlp.fc1.bias"], act=ACT_GELU, want_pre=train, flags=GEMM_PRE_IS_GRAD)
-        if nxt is not None and _GEMM_LN and ops.gemm_res_ln_supported(d, w1.shape[0], dt):
+        if nxt is not None and _GEMM_LN and ops.gemm_res_ln_prefers(x.shape[0], d, w1.shape[0], dt):
             x_out, hn, mean_n, rstd_n = ops.gemm_res_ln(v, w2, P[pre + "mlp.fc2.bias"], x_mid, P[nxt + ".weight"], P[nxt + ".bias"], eps,
                                                         want_stats=train, out=None if train else x_mid)
             ln = (hn, mean_n, rstd_n)

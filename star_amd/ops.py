@@ -231,6 +231,11 @@ def gemm_res_ln_supported(n, k, dt):
     return bool(L.lib().star_gemm_res_ln_supported(n, k, dt))
 
 
+def gemm_res_ln_prefers(m, n, k, dt):
+    """a kernel exists AND is expected to beat star_gemm + star_layernorm_fwd at this M (whole-row tiles: M sets the tile count)"""
+    return bool(L.lib().star_gemm_res_ln_prefers(m, n, k, dt))
+
+
 def gemm_res_ln(a, w, bias, res, gamma, beta, eps, want_stats=True, out=None):
     """x_out = res + a @ w^T + bias (float32) and h = LayerNorm(x_out) * gamma + beta (bf16) in one kernel (star_gemm_res_ln).
     a [M, K], w [N, K] bf16; res float32 [M, N].  Returns (x_out, h, mean, rstd); `out` may be res."""

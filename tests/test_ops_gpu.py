@@ -668,8 +668,11 @@ def test_gemm_res_ln_one_kernel_against_gemm_then_layernorm(m, n, k, monkeypatch
     assert ops.gemm_res_ln_supported(n, k, 0)
     _, x_ref, _ = ops.gemm(a, w, bias=bias, res=res, want_lp=False, want_f32=True)
     h_ref, mean_ref, rstd_ref = ops.layernorm_fwd(x_ref, gamma, beta, 1e-6, 0)
-    for geo in ("0", "1", "2", "3"):
-        monkeypatch.setenv("STAR_AMD_GEMM_LN_GEO", geo)
+    for geo in (None, "0", "1", "2", "3"):      # None: the library's own choice by shape
+        if geo is None:
+            monkeypatch.delenv("STAR_AMD_GEMM_LN_GEO", raising=False)
+        else:
+            monkeypatch.setenv("STAR_AMD_GEMM_LN_GEO", geo)
         x, h, mean, rstd = ops.gemm_res_ln(a, w, bias, res, gamma, beta, 1e-6)
         x64 = res.double() + a.double() @ w.double().t() + bias.double()
         assert (x - x64).abs().max().item() < 2e-5 * max(1.0, x64.abs().max().item())
@@ -690,6 +693,10 @@ def test_gemm_res_ln_one_kernel_against_gemm_then_layernorm(m, n, k, monkeypatch
 
 def test_gemm_res_ln_rejects_unsupported_shapes():
     assert not ops.gemm_res_ln_supported(128, 384, 0) and not ops.gemm_res_ln_supported(384, 40, 0)
+    # whole-row tiles: at small M the two launches are the faster path for the K = 1536 shape, and callers are told so
+    assert ops.gemm_res_ln_prefers(40960, 384, 1536, 0) and not ops.gemm_res_ln_prefers(5120, 384, 1536, 0)
+    assert ops.gemm_res_ln_prefers(5120, 384, 384, 0) and ops.gemm_res_ln_prefers(5120, 256, 1024, 0)
+    assert not ops.gemm_res_ln_prefers(40960, 384, 1536, 1) and not ops.gemm_res_ln_prefers(0, 384, 384, 0)
     assert not ops.gemm_res_ln_supported(384, 384, 1)
     a = torch.zeros(8, 384, device=DEV, dtype=torch.bfloat16)
     w = torch.zeros(128, 384, device=DEV, dtype=torch.bfloat16)
