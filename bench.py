@@ -46,7 +46,7 @@ def parse():
 
 
 # kernel family (ops.Profiler tag) -> kernel-name prefixes in the rocprofv3 PMC summary committed under profiles/
-_FAMILY_KERNELS = {"gemm_nt": ("void gemm_nt_fast_kernel", "void gemm_nt_wreg_kernel", "void gemm_nt_kernel"), "gemm_wgrad": ("void gemm_tn_", "wgrad_reduce_kernel"), "mlp_fwd": ("void mlp_fwd_kernel",),
+_FAMILY_KERNELS = {"gemm_nt": ("void gemm_nt_fast_kernel", "void gemm_nt_wreg_kernel", "void gemm_nt_kernel"), "gemm_wgrad": ("void gemm_tn_", "wgrad_reduce_kernel"), "mlp_fwd": ("void mlp_fwd_kernel",), "gemm_res_ln": ("void gemm_res_ln_kernel",),
                    "attn_fwd": ("void attn_fwd_",), "attn_bwd": ("void attn_bwd_", "void attn_delta_"),
                    "layernorm_fwd": ("void ln_fwd_",), "layernorm_bwd": ("void ln_bwd_", "ln_bwd_reduce"),
                    "ce_argmax": ("void ce_argmax_",), "warp_fuse": ("warp_fuse_", "wf_pack_bits")}
