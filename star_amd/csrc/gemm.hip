@@ -262,6 +262,7 @@ __device__ __forceinline__ int ntf_swz(int row) { return (0x78 >> (((row >> 2) &
 //   <2,2,4>: 128 x 128, 4 waves (3 blocks per CU)   -- narrow outputs (N <= 256) and small problems
 //   <4,2,4>: 256 x 128, 8 waves (2 blocks per CU)   -- N = 384: a 128-wide W panel per tile, 25 % fewer operand bytes per flop
 //   <2,4,8>: 256 x 256, 8 waves (1 block per CU)    -- wide outputs: half the operand bytes per flop
+//   <2,2,2>:  64 x 128, 4 waves                      -- problems with too few 128-row tiles for the chip
 // What bounds the 128 x 128 tile at K = 256..384 is the rate at which a CU takes operand bytes in through LDS-DMA
 // (measured: 12 waves spend 55 % of their cycles issue-stalled, MFMA pipe 24 % busy): every tile re-reads a full
 // 98 KB W panel and A panel for 12.6 MFLOP.  Bigger tiles cut that ratio; the per-wave code is the same.
@@ -646,11 +647,13 @@ static void launch_nt_fast_geo(const StarGemm* g, hipStream_t s) {
 // Geometry by epilogue and shape, from measurements at M = 40 960 on MI355X (profiles/r01_d_gemm_geometry.log):
 //   plain Linear (bias only, bf16 or f32 out): the 256 x 128 tile wins by 10-20 % (no spills at 128 registers, 16 waves per CU);
 //   fc1 + GELU at N >= 1536: the 256 x 256 tile wins by 12 %;  residual / aux epilogues: the 128 x 128 tile (the larger tiles
-//   spill or halve the occupancy).  STAR_AMD_GEMM_GEO=0/1/2 forces one geometry (A/B measurements, tests of every variant).
+//   spill or halve the occupancy); problems whose 128 x 128 tiles cover at most half the CUs: 64 x 128 tiles (M = 5120, N = 384: fc2 + residual
+//   24.9 -> 18.1 us, the fc1 input gradient 19.9 -> 15.5; at M = 10 240 the same shapes lose 5-15 %).  STAR_AMD_GEMM_GEO=0..3 forces one geometry.
 template <int EPI>
 static int nt_geometry(const StarGemm* g) {
     static const char* env = getenv("STAR_AMD_GEMM_GEO");
-    if (env && env[0] >= '0' && env[0] <= '2') return env[0] - '0';
+    if (env && env[0] >= '0' && env[0] <= '3') return env[0] - '0';
+    if ((long long)cdiv(g->M, 128) * cdiv(g->N, 128) * 2 <= star_num_cus()) return 3;   // few tiles: halve them (one-scene inference)
     if (EPI == EPI_LINEAR && (long long)cdiv(g->M, 256) * cdiv(g->N, 128) >= star_num_cus()) return 1;
     if (EPI == EPI_GELU_GRAD && g->N >= 1536 && (long long)cdiv(g->M, 256) * cdiv(g->N, 256) >= 2 * star_num_cus()) return 2;
     return 0;
@@ -661,6 +664,7 @@ static void launch_nt_fast_epi(const StarGemm* g, hipStream_t s) {
     switch (EPI == EPI_GENERIC ? 0 : nt_geometry<EPI>(g)) {   // the run-time epilogue needs too many registers for the larger tiles
         case 2: launch_nt_fast_geo<NST, EPI, 2, 4, 8>(g, s); break;
         case 1: launch_nt_fast_geo<NST, EPI, 4, 2, 4>(g, s); break;
+        case 3: launch_nt_fast_geo<NST, EPI, 2, 2, 2>(g, s); break;
         default: launch_nt_fast_geo<NST, EPI, 2, 2, 4>(g, s); break;
     }
 }
