@@ -335,7 +335,8 @@ class _LnFolds:
 
 # The fc2 weight gradient of a block is queued on the side stream right before the block's attention backward (compute-bound, the
 # best partner for it) instead of beside the memory-bound dgrad GEMMs and LayerNorm in between; the other three start as soon as
-# their operands exist.  A/B inside one GPU call: this order 12.75 ms/step, all three early ones deferred 12.85, none 12.92.
+# their operands exist.  A/B inside one GPU call: this order 12.75 ms/step, all three early ones deferred 12.85, none 12.92; on the final
+# round-2 build: this order 11.72, fc1 instead of fc2 held back 11.85, both 11.85.
 WG_DEFER = os.environ.get("STAR_AMD_WG_DEFER", "1") == "1"
 # the weight gradients outside the blocks (prediction heads, decoder_embed, decompressor, compressor) run on the side stream too:
 # A/B inside one GPU call 13.51 -> 13.35 ms/step
