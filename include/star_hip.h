@@ -248,11 +248,18 @@ int star_cast_back(const void* src, float* dst, int64_t n, int dt, void* stream)
 /* The per-step refresh of every low-precision weight copy in one launch.  jobs_dev: device array, sorted by
  * tile_start (running count of 64x64 tiles, first = 0); total_tiles = sum over jobs of ceil(rows/64)*ceil(cols/64). */
 typedef struct StarCastJob {
-    const float* src;   /* float32 [rows, cols] */
-    void* dst;          /* dt [rows, cols], or [cols, rows] when transpose != 0 */
+    const float* src;        /* float32 [*, cols]; row r of the job is src row (src_rows ? src_rows[r] : r) */
+    void* dst;               /* dt (float32 when dst_f32 != 0): element (r, c) goes to dst[dst_off + r * dst_ld + c], or to
+                                dst[dst_off + c * dst_ld + r] when transpose != 0 */
     int32_t rows, cols;
     int32_t transpose;
     int32_t tile_start;
+    const int32_t* src_rows; /* optional [rows]: row gather (the fused prediction-head weight takes the rows of two Linear
+                                weights in class-major order) */
+    int32_t dst_ld;          /* leading dimension of dst; 0 = dense (cols, or rows when transposed) */
+    int32_t dst_off;         /* element offset into dst: several jobs can fill one destination */
+    int32_t dst_f32;         /* != 0: this job's destination is float32 whatever dt says (bias vectors) */
+    int32_t reserved;
 } StarCastJob;
 int star_cast_batch(const StarCastJob* jobs_dev, int njobs, int total_tiles, int dt, void* stream);
 /* AdamW (decoupled weight decay) over one flat float32 buffer, torch.optim.AdamW semantics

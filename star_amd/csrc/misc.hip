@@ -71,6 +71,40 @@ extern "C" int star_cast(const float* src, void* dst, int64_t n, int dt, void* s
 
 // All weight copies of a training step in ONE launch: job j converts float32 [rows, cols] to dt, as is or transposed
 // ([cols, rows]), in 64 x 64 tiles; tile_start is the running tile count (jobs sorted, last entry = total).
+template <typename T, typename D>
+__device__ __forceinline__ void cast_tile(const StarCastJob& job, D* __restrict__ dst, float (&tile)[64][65], int r0, int c0) {
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int ld = job.dst_ld > 0 ? job.dst_ld : (job.transpose ? job.rows : job.cols);
+    dst += job.dst_off;
+    if (!job.transpose) {
+#pragma unroll 4
+        for (int i = ty; i < 64; i += 4) {
+            const int r = r0 + i, c = c0 + tx;
+            if (r < job.rows && c < job.cols) {
+                const int sr = job.src_rows ? job.src_rows[r] : r;
+                Act<D>::st(dst + (size_t)r * ld + c, job.src[(size_t)sr * job.cols + c]);
+            }
+        }
+        return;
+    }
+#pragma unroll 4
+    for (int i = ty; i < 64; i += 4) {
+        const int r = r0 + i, c = c0 + tx;
+        float v = 0.f;
+        if (r < job.rows && c < job.cols) {
+            const int sr = job.src_rows ? job.src_rows[r] : r;
+            v = job.src[(size_t)sr * job.cols + c];
+        }
+        tile[i][tx] = v;
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int i = ty; i < 64; i += 4) {
+        const int c = c0 + i, r = r0 + tx;
+        if (r < job.rows && c < job.cols) Act<D>::st(dst + (size_t)c * ld + r, tile[tx][i]);
+    }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void cast_batch_kernel(const StarCastJob* __restrict__ jobs, int njobs) {
     __shared__ float tile[64][65];
@@ -79,27 +113,8 @@ __global__ __launch_bounds__(256) void cast_batch_kernel(const StarCastJob* __re
     const StarCastJob job = jobs[j];
     const int tc = (job.cols + 63) >> 6;
     const int t = blockIdx.x - job.tile_start, r0 = (t / tc) << 6, c0 = (t % tc) << 6;
-    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-    T* dst = (T*)job.dst;
-    if (!job.transpose) {
-#pragma unroll 4
-        for (int i = ty; i < 64; i += 4) {
-            const int r = r0 + i, c = c0 + tx;
-            if (r < job.rows && c < job.cols) Act<T>::st(dst + (size_t)r * job.cols + c, job.src[(size_t)r * job.cols + c]);
-        }
-        return;
-    }
-#pragma unroll 4
-    for (int i = ty; i < 64; i += 4) {
-        const int r = r0 + i, c = c0 + tx;
-        tile[i][tx] = (r < job.rows && c < job.cols) ? job.src[(size_t)r * job.cols + c] : 0.f;
-    }
-    __syncthreads();
-#pragma unroll 4
-    for (int i = ty; i < 64; i += 4) {
-        const int c = c0 + i, r = r0 + tx;
-        if (r < job.rows && c < job.cols) Act<T>::st(dst + (size_t)c * job.rows + r, tile[tx][i]);
-    }
+    if (job.dst_f32) cast_tile<T, float>(job, (float*)job.dst, tile, r0, c0);      // block-uniform branch
+    else cast_tile<T, T>(job, (T*)job.dst, tile, r0, c0);
 }
 
 extern "C" int star_cast_batch(const StarCastJob* jobs_dev, int njobs, int total_tiles, int dt, void* stream) {

@@ -53,16 +53,18 @@ class Config:
 _HEAD_PERM = {}
 
 
-def head_permutation(cfg, device):
+def head_permutation(cfg, device, as_int64=False):
     """Row order of the fused prediction-head weight.  Reference rows are (py, px, c) per class
     (mae_base.py:392-406 un-patchify order); the kernels want class-major (c, py, px) so that the 8
-    voxels of a patch row are contiguous.  Returns idx with new_row[n] = old_row[idx[n]]."""
+    voxels of a patch row are contiguous.  Returns idx with new_row[n] = old_row[idx[n]] (int32 for the cast jobs, int64 for torch
+    indexing)."""
     p, c = cfg.patch, cfg.chans
     key = (p, c, str(device))
+    key = key + (bool(as_int64),)
     idx = _HEAD_PERM.get(key)
     if idx is None:   # built once: a host-to-device copy in the middle of the backward pass would stall the launch queue
         cc, py, px = torch.meshgrid(torch.arange(c), torch.arange(p), torch.arange(p), indexing="ij")
-        idx = _HEAD_PERM[key] = ((py * p + px) * c + cc).reshape(-1).to(device)
+        idx = _HEAD_PERM[key] = ((py * p + px) * c + cc).reshape(-1).to(torch.int64 if as_int64 else torch.int32).to(device)
     return idx
 
 
@@ -74,30 +76,42 @@ class Weights:
     def __init__(self):
         self.cache = {}
         self.epoch = 0
-        self.plain = {}      # key -> [param, dst, transposed, versions]: plain casts, refreshed together in one launch
+        self.plain = {}      # key -> entry: copies that are cast jobs, refreshed together in ONE launch
         self.table = None    # (device job table, njobs, tiles, dt, signature)
 
-    def linear(self, key, w, dt, transposed):
-        """The dt copy of weight `w` ([N,K], or [K,N] when transposed).  A stale copy triggers ONE batched launch that
+    def jobs_entry(self, key, params, dt, make):
+        """The copy registered under `key` (key[1] = dt), built from `params` by cast jobs.  make() -> (dst, jobs) allocates the
+        destination and lists its jobs (ops.cast_batch_table tuples) on first use.  A stale copy triggers ONE batched launch that
         refreshes every registered copy (they all go stale together: one optimizer step)."""
-        versions = (w._version, self.epoch)
+        versions = tuple(q._version for q in params) + (self.epoch,)
+        ptrs = tuple(q.data_ptr() for q in params)
         ent = self.plain.get(key)
-        if ent is not None and ent[0].data_ptr() == w.data_ptr() and ent[3] == versions:
-            return ent[1]
-        if ent is None or ent[0].data_ptr() != w.data_ptr() or ent[1].device != w.device:
-            dst = ops.cast_transpose(w.detach(), dt) if transposed else ops.cast(w.detach(), dt)
-            self.plain[key] = [w, dst, transposed, versions]
+        if ent is not None and ent["ptrs"] == ptrs and ent["versions"] == versions:
+            return ent["dst"]
+        if ent is None or ent["ptrs"] != ptrs or ent["dst"].device != params[0].device:
+            dst, jobs = make()
+            tab, n, tiles = ops.cast_batch_table(jobs, params[0].device)
+            ops.cast_batch(tab, n, tiles, dt)
+            self.plain[key] = dict(ptrs=ptrs, params=params, dst=dst, jobs=jobs, versions=versions)
             self.table = None
             return dst
         same_dt = [e for k, e in self.plain.items() if k[1] == dt]
-        sig = tuple((e[0].data_ptr(), e[1].data_ptr()) for e in same_dt)
+        sig = tuple((e["ptrs"], e["dst"].data_ptr()) for e in same_dt)
         if self.table is None or self.table[3] != dt or self.table[4] != sig:
-            tab, n, tiles = ops.cast_batch_table([(e[0].detach(), e[1], e[2]) for e in same_dt], w.device)
+            tab, n, tiles = ops.cast_batch_table([j for e in same_dt for j in e["jobs"]], params[0].device)
             self.table = (tab, n, tiles, dt, sig)
         ops.cast_batch(self.table[0], self.table[1], self.table[2], dt)
         for e in same_dt:
-            e[3] = (e[0]._version, self.epoch)
-        return ent[1]
+            e["versions"] = tuple(q._version for q in e["params"]) + (self.epoch,)
+        return ent["dst"]
+
+    def linear(self, key, w, dt, transposed):
+        """The dt copy of weight `w` ([N,K], or [K,N] when transposed)."""
+        def make():
+            n, k = w.shape
+            dst = torch.empty((k, n) if transposed else (n, k), dtype=ops.L.torch_dtype(dt), device=w.device)
+            return dst, [(w.detach(), dst, transposed)]
+        return self.jobs_entry(key, (w,), dt, make)
 
     def get(self, key, versions, build):
         versions = (versions, self.epoch)
@@ -115,25 +129,36 @@ def _lin(P, W, name, dt, transposed=False):
 
 
 def _heads(P, W, cfg, dt, transposed=False):
+    """The two prediction heads as ONE Linear in the kernels' class-major row order: rows [0, V) = decoder_pred_free, [V, 2V) =
+    decoder_pred_occ, each gathered through head_permutation -- two jobs of the step's batched weight refresh (no launches of
+    their own)."""
     wo, wf = P["decoder_pred_occ.weight"], P["decoder_pred_free.weight"]
-    key = ("heads", dt, transposed)
 
-    def build():
+    def make():
         idx = head_permutation(cfg, wo.device)
-        fused = torch.cat([wf.detach().index_select(0, idx), wo.detach().index_select(0, idx)], 0).contiguous()
-        return ops.cast_transpose(fused, dt) if transposed else ops.cast(fused, dt)
+        v, k = wf.shape
+        dst = torch.empty((k, 2 * v) if transposed else (2 * v, k), dtype=ops.L.torch_dtype(dt), device=wo.device)
+        if transposed:
+            return dst, [(wf.detach(), dst, True, dict(src_rows=idx, dst_ld=2 * v, dst_off=0)),
+                         (wo.detach(), dst, True, dict(src_rows=idx, dst_ld=2 * v, dst_off=v))]
+        return dst, [(wf.detach(), dst, False, dict(src_rows=idx, dst_ld=k, dst_off=0)),
+                     (wo.detach(), dst, False, dict(src_rows=idx, dst_ld=k, dst_off=v * k))]
 
-    return W.get(key, (wo._version, wf._version), build)
+    return W.jobs_entry(("heads", dt, transposed), (wf, wo), dt, make)
 
 
-def _heads_bias(P, W, cfg):
+def _heads_bias(P, W, cfg, dt):
+    """float32 bias of the fused heads, same row order; rides in the batched refresh of the dt copies."""
     bo, bf = P["decoder_pred_occ.bias"], P["decoder_pred_free.bias"]
 
-    def build():
+    def make():
         idx = head_permutation(cfg, bo.device)
-        return torch.cat([bf.detach().index_select(0, idx), bo.detach().index_select(0, idx)], 0).contiguous()
+        v = bf.numel()
+        dst = torch.empty(2 * v, dtype=torch.float32, device=bo.device)
+        return dst, [(bf.detach().reshape(v, 1), dst, False, dict(src_rows=idx, dst_ld=1, dst_off=0, dst_f32=True)),
+                     (bo.detach().reshape(v, 1), dst, False, dict(src_rows=idx, dst_ld=1, dst_off=v, dst_f32=True))]
 
-    return W.get(("heads_bias",), (bo._version, bf._version), build)
+    return W.jobs_entry(("heads_bias", dt, False), (bf, bo), dt, make)
 
 
 def _patch_weight(P, W, cfg, dt, channels_last):
@@ -463,7 +488,7 @@ def forward(cfg, P, W, dt, imgs1, imgs_next, trans_matrices, num_agent, batch, m
                                          train, taps, "dec_blk%d")
     if taps is not None:
         taps["dec_norm"] = yd.clone()
-    _, logits, _ = ops.gemm(yd, _heads(P, W, cfg, dt), bias=_heads_bias(P, W, cfg), want_lp=False, want_f32=True)
+    _, logits, _ = ops.gemm(yd, _heads(P, W, cfg, dt), bias=_heads_bias(P, W, cfg, dt), want_lp=False, want_f32=True)
 
     # ---- loss, decision, fusion (K9, K10) -----------------------------------------------------------------------
     ce = ops.ce_argmax(logits, imgs1, p, dt, want_pred=taps is not None, want_dlogits=train)
@@ -509,15 +534,14 @@ def backward(cfg, P, W, dt, ctx, G=None, on_ready=None):
 
     def heads_wgrad():
         dw, db = ops.gemm_wgrad(dlog, ctx["yd"])
-        idx = head_permutation(cfg, dw.device)
+        idx = head_permutation(cfg, dw.device, as_int64=True)
         V = cfg.V
-        for name, lo in (("decoder_pred_free", 0), ("decoder_pred_occ", V)):
-            gw = torch.empty(V, Dd, dtype=torch.float32, device=dw.device)
-            gb = torch.empty(V, dtype=torch.float32, device=dw.device)
+        for name, lo in (("decoder_pred_free", 0), ("decoder_pred_occ", V)):     # rows back in the reference order, straight into G
+            gw = G[name + ".weight"] if G is not None else torch.empty(V, Dd, dtype=torch.float32, device=dw.device)
+            gb = G[name + ".bias"] if G is not None else torch.empty(V, dtype=torch.float32, device=dw.device)
             gw.index_copy_(0, idx, dw[lo:lo + V])
             gb.index_copy_(0, idx, db[lo:lo + V])
-            _put(grads, G, name + ".weight", gw)
-            _put(grads, G, name + ".bias", gb)
+            grads[name + ".weight"], grads[name + ".bias"] = gw, gb
     if side_x is None:
         heads_wgrad()
     else:
@@ -584,15 +608,23 @@ def backward(cfg, P, W, dt, ctx, G=None, on_ready=None):
             on_ready(stage)
     # patch embedding
     wshape = P["patch_embed.proj.weight"].shape
+    wname, bname = "patch_embed.proj.weight", "patch_embed.proj.bias"
+    # written in place where the layouts allow it: the weight gradient unless its columns come in (py, px, c) order, the bias always
+    dw_out = G[wname].view(wshape[0], -1) if (G is not None and not ctx["channels_last"]) else None
     if cfg.encode_partial:
-        dw, _ = ops.gemm_wgrad(g_lp, ctx["a_pe"], x_rows=ctx["src_row"], want_bias=False)
+        dw, _ = ops.gemm_wgrad(g_lp, ctx["a_pe"], x_rows=ctx["src_row"], want_bias=False, dw=dw_out)
         db = ops.colsum_groups(g, 1, 1, sel=ctx["src_row"], sel_nonneg=True).reshape(-1)   # padded slots carry no bias
+        _put(grads, G, bname, db)
     else:
-        dw, db = ops.gemm_wgrad(g_lp, ctx["a_pe"])
+        dw, db = ops.gemm_wgrad(g_lp, ctx["a_pe"], dw=dw_out, db=None if G is None else G[bname])
+        grads[bname] = db
     if ctx["channels_last"]:
-        dw = dw.reshape(wshape[0], wshape[2], wshape[3], wshape[1]).permute(0, 3, 1, 2).contiguous()
-    _put(grads, G, "patch_embed.proj.weight", dw.reshape(wshape))
-    _put(grads, G, "patch_embed.proj.bias", db)
+        dw = dw.reshape(wshape[0], wshape[2], wshape[3], wshape[1]).permute(0, 3, 1, 2)    # strided view: ONE copy into G (or below)
+        if G is None:
+            dw = dw.contiguous()
+        _put(grads, G, wname, dw)
+    else:
+        grads[wname] = G[wname] if G is not None else dw.reshape(wshape)
     if fold is not None:
         fold.run()
     if side is not None:

@@ -418,12 +418,22 @@ def cast(src, dt):
 
 
 def cast_batch_table(jobs, device):
-    """jobs: list of (src float32 [R,C], dst, transposed).  -> (int64 device table, njobs, total_tiles) for cast_batch."""
+    """jobs: list of (src float32 [R,C], dst, transposed[, extras]) with extras = dict(src_rows=int32 tensor [rows] (row gather: the
+    job has that many rows), dst_ld, dst_off (elements), dst_f32).  -> (int64 device table, njobs, total_tiles) for cast_batch."""
     rows, start = [], 0
-    for src, dst, tr in jobs:
-        r, c = src.shape
-        assert src.dtype == torch.float32 and src.is_contiguous() and dst.is_contiguous() and dst.numel() == r * c
-        rows.append([src.data_ptr(), dst.data_ptr(), r | (c << 32), int(bool(tr)) | (start << 32)])   # StarCastJob, little endian
+    for job in jobs:
+        src, dst, tr = job[:3]
+        ex = job[3] if len(job) > 3 else {}
+        idx = ex.get("src_rows")
+        r, c = (idx.numel() if idx is not None else src.shape[0]), src.shape[1]
+        assert src.dtype == torch.float32 and src.is_contiguous() and dst.is_contiguous()
+        assert idx is None or (idx.dtype == torch.int32 and idx.is_contiguous() and idx.device == dst.device)
+        ld, off = int(ex.get("dst_ld", 0)), int(ex.get("dst_off", 0))
+        last = off + ((c - 1) * (ld or r) + r if tr else (r - 1) * (ld or c) + c)
+        assert 0 <= off and last <= dst.numel(), "cast job writes past its destination"
+        assert dst.dtype == (torch.float32 if ex.get("dst_f32") else dst.dtype) and (ex or dst.numel() == r * c)
+        rows.append([src.data_ptr(), dst.data_ptr(), r | (c << 32), int(bool(tr)) | (start << 32),      # StarCastJob, little endian
+                     idx.data_ptr() if idx is not None else 0, ld | (off << 32), int(bool(ex.get("dst_f32")))])
         start += ((r + 63) // 64) * ((c + 63) // 64)
     return torch.tensor(rows, dtype=torch.int64).to(device), len(jobs), start
 

@@ -518,6 +518,26 @@ def test_cast_batch_matches_single_casts():
         for src, dst, tr in jobs:
             want = ops.cast_transpose(src, dt) if tr else ops.cast(src, dt)
             assert torch.equal(dst, want), (src.shape, tr)
+        # row-gathered jobs that share one destination (the fused prediction-head weight: two Linear weights, class-major rows), plain
+        # and transposed, plus a float32 job (its bias) in the same launch
+        v, k = 832, 256
+        a, b = torch.randn(v, k, generator=g).to(DEV), torch.randn(v, k, generator=g).to(DEV)
+        ba, bb = torch.randn(v, generator=g).to(DEV), torch.randn(v, generator=g).to(DEV)
+        idx = torch.randperm(v, generator=g).to(torch.int32).to(DEV)
+        plain = torch.full((2 * v, k), 7.0, dtype=td, device=DEV)
+        trans = torch.full((k, 2 * v), 7.0, dtype=td, device=DEV)
+        bias = torch.full((2 * v,), 7.0, dtype=torch.float32, device=DEV)
+        jobs = [(a, plain, False, dict(src_rows=idx, dst_ld=k, dst_off=0)), (b, plain, False, dict(src_rows=idx, dst_ld=k, dst_off=v * k)),
+                (a, trans, True, dict(src_rows=idx, dst_ld=2 * v, dst_off=0)), (b, trans, True, dict(src_rows=idx, dst_ld=2 * v, dst_off=v)),
+                (ba.reshape(v, 1), bias, False, dict(src_rows=idx, dst_ld=1, dst_off=0, dst_f32=True)),
+                (bb.reshape(v, 1), bias, False, dict(src_rows=idx, dst_ld=1, dst_off=v, dst_f32=True))]
+        tab, n, tiles = ops.cast_batch_table(jobs, DEV)
+        ops.cast_batch(tab, n, tiles, dt)
+        want = torch.cat([a[idx.long()], b[idx.long()]], 0)
+        assert torch.equal(plain, ops.cast(want, dt)) and torch.equal(trans, ops.cast_transpose(want, dt))
+        assert torch.equal(bias, torch.cat([ba[idx.long()], bb[idx.long()]]))
+    with pytest.raises(AssertionError, match="past its destination"):
+        ops.cast_batch_table([(torch.zeros(8, 8, device=DEV), torch.zeros(8, 8, device=DEV), False, dict(dst_ld=8, dst_off=1))], DEV)
 
 
 def test_warp_fuse_full_size_vs_c_oracle():
