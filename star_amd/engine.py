@@ -280,9 +280,12 @@ class _SideStream:
         self.stream = _SideStream.streams[device]
         self.used = False
 
-    def run(self, fn, *tensors):
+    def run(self, fn, *tensors, wait=True):
+        """wait=False: every input was produced BEFORE an earlier run() on this stream waited for the caller's stream (a cross-stream
+        wait costs the caller's stream ~10 us: tools/probe_event_cost.py)."""
         main = torch.cuda.current_stream(self.device)
-        self.stream.wait_stream(main)                 # inputs are produced on the caller's stream
+        if wait:
+            self.stream.wait_stream(main)             # inputs are produced on the caller's stream
         with torch.cuda.stream(self.stream):
             out = fn()
         for t in tensors:
@@ -302,7 +305,7 @@ _MLP_FUSED = os.environ.get("STAR_AMD_MLP_FUSED", "0") == "1"       # the block 
 _SKIP_WGRAD = os.environ.get("STAR_AMD_SKIP_WGRAD", "0") == "1"   # measurement only (wrong gradients): the backward chain without its weight-gradient GEMMs
 
 
-def _wg(grads, G, name, dy, x, x_rows=None, side=None):
+def _wg(grads, G, name, dy, x, x_rows=None, side=None, wait=True):
     """weight + bias gradient of Linear `name`, written into the caller's gradient views when given."""
     if _SKIP_WGRAD and G is not None:
         grads[name + ".weight"], grads[name + ".bias"] = G[name + ".weight"], G[name + ".bias"]
@@ -311,7 +314,7 @@ def _wg(grads, G, name, dy, x, x_rows=None, side=None):
     def run():
         return ops.gemm_wgrad(dy, x, x_rows=x_rows, dw=None if G is None else G[name + ".weight"],
                               db=None if G is None else G[name + ".bias"])
-    dw, db = run() if side is None else side.run(run, dy, x, x_rows)
+    dw, db = run() if side is None else side.run(run, dy, x, x_rows, wait=wait)
     grads[name + ".weight"], grads[name + ".bias"] = dw, db
 
 
@@ -382,8 +385,8 @@ def _block_bwd(g, g_lp, s, P, W, dt, grads, G=None, side=None, fold=None):
     g1, g1_lp = _ln_bwd(grads, G, pre + "norm2", dh2, s["x_mid"], P, s["mean2"], s["rstd2"], g_in=g, fold=fold)
     _wg(grads, G, pre + "attn.proj", g1_lp, s["a"], side=side)
     da, _, _ = ops.gemm(g1_lp, _lin(P, W, pre + "attn.proj", dt, True))
-    for a, k in late:          # the held-back fc2 weight gradient starts beside the attention backward
-        _wg(*a, **k)
+    for a, k in late:          # the held-back fc2 weight gradient starts beside the attention backward; its operands are older than
+        _wg(*a, wait=False, **k)   # the side stream's last wait (fc1 / proj above), so it needs no cross-stream wait of its own
     dqkv = ops.attn_bwd(s["qkv"], s["a"], da, s["lse"], nb, l, heads, hd)
     _wg(grads, G, pre + "attn.qkv", dqkv, s["h1"], side=side)
     dh1, _, _ = ops.gemm(dqkv, _lin(P, W, pre + "attn.qkv", dt, True))
