@@ -271,7 +271,7 @@ static int res_ln_geometry(int M, int N, int K) {
 }
 
 extern "C" int star_gemm_res_ln_prefers(int M, int N, int K, int dt) {
-    return star_gemm_res_ln_supported(N, K, dt) && M > 0 && res_ln_geometry(M, N, K) >= 0;
+    return star_gemm_res_ln_supported(N, K, dt) && M > 0 && (long long)M * K * 2 < 0x7fffffffLL && res_ln_geometry(M, N, K) >= 0;
 }
 
 extern "C" int star_gemm_res_ln(const void* A, const void* W, const float* bias, const float* res, float* x_out,
