@@ -1029,12 +1029,14 @@ __global__ __launch_bounds__(GT) void gemm_tn_bf16_kernel(const bf16_t* __restri
 // of the matrices are zero-filled by the buffer range check (splits are multiples of 32 rows, so a stage
 // never straddles two splits).  The bias gradient costs no memory traffic at all: in the k-tile-0 blocks
 // one extra MFMA per n-tile multiplies the dY fragment with an all-ones A operand (row sums on the matrix core).
-template <int NST>
-__global__ __launch_bounds__(GT) void gemm_tn_fast_kernel(const bf16_t* __restrict__ dY, const bf16_t* __restrict__ X,
+template <int NST, int NWV>
+__global__ __launch_bounds__(NWV * 64) void gemm_tn_fast_kernel(const bf16_t* __restrict__ dY, const bf16_t* __restrict__ X,
                                                           float* __restrict__ out, float* __restrict__ bias_part, int M, int N, int K,
                                                           int m_per_split) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr int TB = 32 * 256, STAGE = 2 * TB, PF = NST - 1;
+    // NWV waves: 2 over k x NWV/2 over n; a wave owns 64 (k) x 128/(NWV/2) (n) of the 128 x 128 tile
+    constexpr int TB = 32 * 256, STAGE = 2 * TB, PF = NST - 1, NJ = 8 / NWV, NB = 16 / NWV, RPW = 32 / NWV;
+    static_assert(NWV == 4 || NWV == 8, "4 or 8 waves");
     // XCD-aware order: all output tiles of one split read the same rows of dY and X, so a split's tiles run on ONE XCD
     // (one L2 fetch per row block instead of one per XCD; measured 361 -> ~1x the operand bytes per launch)
     const int tiles_n = (N + WG_TILE - 1) / WG_TILE, tiles = tiles_n * ((K + WG_TILE - 1) / WG_TILE);
@@ -1051,8 +1053,8 @@ __global__ __launch_bounds__(GT) void gemm_tn_fast_kernel(const bf16_t* __restri
     __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(X), 0, (unsigned)((long long)M * K * 2), 0x00020000);
     unsigned offY[2], offX[2];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int r = wave * 8 + j * 4 + (lane >> 4);       // row inside the 32-row stage
+    for (int j = 0; j < NJ; ++j) {
+        const int r = wave * RPW + j * 4 + (lane >> 4);       // row inside the 32-row stage
         const int pc = lane & 15;
         const int col = (((pc >> 1) ^ tn_swz(r)) << 4) + ((pc & 1) << 3);
         offY[j] = n_blk + col < N ? (unsigned)(((long long)(m_begin + r) * N + n_blk + col) * 2) : 0x80000000u;
@@ -1062,95 +1064,94 @@ __global__ __launch_bounds__(GT) void gemm_tn_fast_kernel(const bf16_t* __restri
     auto issue = [&](int st_) {
         unsigned char* sb = smem + (st_ % NST) * STAGE;
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsY, (__attribute__((address_space(3))) void*)(sb + (wave * 8 + j * 4) * 256), 16,
+        for (int j = 0; j < NJ; ++j) {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsY, (__attribute__((address_space(3))) void*)(sb + (wave * RPW + j * 4) * 256), 16,
                                                      offY[j] + st_ * stepY, 0, 0, 0);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, (__attribute__((address_space(3))) void*)(sb + TB + (wave * 8 + j * 4) * 256), 16,
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, (__attribute__((address_space(3))) void*)(sb + TB + (wave * RPW + j * 4) * 256), 16,
                                                      offX[j] + st_ * stepX, 0, 0, 0);
         }
     };
-    f32x4_t acc[4][4], accb[4];
+    f32x4_t acc[4][NB], accb[NB];
 #pragma unroll
-    for (int a = 0; a < 4; ++a) {
-        accb[a] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    for (int b = 0; b < NB; ++b) {
+        accb[b] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int b = 0; b < 4; ++b) acc[a][b] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        for (int a = 0; a < 4; ++a) acc[a][b] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
     }
     const bool do_bias = bias_part != nullptr && k_blk == 0 && wk == 0;
     const short one = (short)0x3F80;
     const short8_t ones = (short8_t){one, one, one, one, one, one, one, one};
     const int r0 = lg * 8 + lq;
-    int ax[4], ay[4];
+    // rows r0 and r0+4 share the swizzle bits (row&3) only partly: the +4 variants are computed, not offset
+    int ax[4], axh[4], ay[NB], ayh[NB];
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
         ax[a] = TB + tn_off(r0, wk * 4 + a) + lp * 8;
-        ay[a] = tn_off(r0, wn * 4 + a) + lp * 8;
-    }
-    // rows r0 and r0+4 share the swizzle bits (row&3) only partly: recompute the +4 variants
-    int axh[4], ayh[4];
-#pragma unroll
-    for (int a = 0; a < 4; ++a) {
         axh[a] = TB + tn_off(r0 + 4, wk * 4 + a) + lp * 8;
-        ayh[a] = tn_off(r0 + 4, wn * 4 + a) + lp * 8;
+    }
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        ay[b] = tn_off(r0, wn * NB + b) + lp * 8;
+        ayh[b] = tn_off(r0 + 4, wn * NB + b) + lp * 8;
     }
     const unsigned lds_base = lds_u32(smem);
     const int nsteps = (m_end - m_begin + 31) / 32;
     for (int s0 = 0; s0 < PF && s0 < nsteps; ++s0) issue(s0);
     for (int st = 0; st < nsteps; ++st) {
         const int rem = min(nsteps - 1 - st, PF - 1);
-        if (rem >= 3) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-        else if (rem == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        else if (rem == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        if (rem >= 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(6 * NJ) : "memory");      // 2 NJ LDS-DMA loads per wave and stage
+        else if (rem == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * NJ) : "memory");
+        else if (rem == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NJ) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         if (st + PF < nsteps) issue(st + PF);
         // transposed reads as inline asm (common.h): the builtin would make the compiler drain the DMA ring (vmcnt(0))
         const unsigned sb = lds_base + (st % NST) * STAGE;
-        short4_t xl[4], xh[4], yl[4], yh[4];
+        short4_t xl[4], xh[4], yl[NB], yh[NB];
 #pragma unroll
         for (int a = 0; a < 4; ++a) {
             xl[a] = tr16<0>(sb + ax[a]);
             xh[a] = tr16<0>(sb + axh[a]);
         }
 #pragma unroll
-        for (int b = 0; b < 4; ++b) {
+        for (int b = 0; b < NB; ++b) {
             yl[b] = tr16<0>(sb + ay[b]);
             yh[b] = tr16<0>(sb + ayh[b]);
         }
         asm volatile("s_waitcnt lgkmcnt(0)"
                      : "+v"(xl[0]), "+v"(xl[1]), "+v"(xl[2]), "+v"(xl[3]), "+v"(xh[0]), "+v"(xh[1]), "+v"(xh[2]), "+v"(xh[3]));
-        asm volatile("" : "+v"(yl[0]), "+v"(yl[1]), "+v"(yl[2]), "+v"(yl[3]), "+v"(yh[0]), "+v"(yh[1]), "+v"(yh[2]), "+v"(yh[3]));
-        short8_t fx[4], fy[4];
+        if constexpr (NB == 4) asm volatile("" : "+v"(yl[0]), "+v"(yl[1]), "+v"(yl[2]), "+v"(yl[3]), "+v"(yh[0]), "+v"(yh[1]), "+v"(yh[2]), "+v"(yh[3]));
+        else asm volatile("" : "+v"(yl[0]), "+v"(yl[1]), "+v"(yh[0]), "+v"(yh[1]));
+        short8_t fx[4], fy[NB];
 #pragma unroll
-        for (int a = 0; a < 4; ++a) {
-            fx[a] = (short8_t){xl[a][0], xl[a][1], xl[a][2], xl[a][3], xh[a][0], xh[a][1], xh[a][2], xh[a][3]};
-            fy[a] = (short8_t){yl[a][0], yl[a][1], yl[a][2], yl[a][3], yh[a][0], yh[a][1], yh[a][2], yh[a][3]};
-        }
+        for (int a = 0; a < 4; ++a) fx[a] = (short8_t){xl[a][0], xl[a][1], xl[a][2], xl[a][3], xh[a][0], xh[a][1], xh[a][2], xh[a][3]};
+#pragma unroll
+        for (int b = 0; b < NB; ++b) fy[b] = (short8_t){yl[b][0], yl[b][1], yl[b][2], yl[b][3], yh[b][0], yh[b][1], yh[b][2], yh[b][3]};
 #pragma unroll
         for (int a = 0; a < 4; ++a)
 #pragma unroll
-            for (int b = 0; b < 4; ++b)
+            for (int b = 0; b < NB; ++b)
                 acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, fx[a]), __builtin_bit_cast(bf16x8_t, fy[b]),
                                                                     acc[a][b], 0, 0, 0);
         if (do_bias) {
 #pragma unroll
-            for (int b = 0; b < 4; ++b)
+            for (int b = 0; b < NB; ++b)
                 accb[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, ones), __builtin_bit_cast(bf16x8_t, fy[b]),
                                                                   accb[b], 0, 0, 0);
         }
     }
     if (do_bias && lg == 0) {
 #pragma unroll
-        for (int b = 0; b < 4; ++b) {
-            const int n = n_blk + wn * 64 + b * 16 + (lane & 15);
+        for (int b = 0; b < NB; ++b) {
+            const int n = n_blk + wn * (NB * 16) + b * 16 + (lane & 15);
             if (n < N) bias_part[(size_t)split * N + n] = accb[b][0];
         }
     }
     float* o = out + (size_t)split * N * K;
 #pragma unroll
-    for (int b = 0; b < 4; ++b) {
-        const int n = n_blk + wn * 64 + b * 16 + (lane & 15);
+    for (int b = 0; b < NB; ++b) {
+        const int n = n_blk + wn * (NB * 16) + b * 16 + (lane & 15);
         if (n >= N) continue;
 #pragma unroll
         for (int a = 0; a < 4; ++a) {
@@ -1267,6 +1268,7 @@ static void wgrad_plan(int M, int N, int K, int dt, int* S, int* m_per, int* SC,
     // about one block per CU (256 CUs): alone on the chip twice as many blocks run a weight gradient ~5 % faster, but inside
     // the training step -- where it shares the CUs with the main backward chain -- the smaller launch is the better neighbour
     // (12.97 -> 12.89 ms/step; 150 % of the old target: 13.14) and halves the slab traffic (S x N x K x 8 bytes)
+    // (re-measured with the 8-wave kernel of round 2: 75 % of this target 11.99-12.04 ms, 100 % 11.95-11.99, 150 % 12.06-12.09, 50 % 12.36)
     const int target = tiles <= 9 ? 128 : (tiles <= 16 ? 192 : 256);
     int s = cdiv(target, tiles);
     const int max_s = cdiv(M, 8 * step);       // at least 8 reduction steps per split
@@ -1308,8 +1310,15 @@ extern "C" int star_gemm_wgrad(const void* dY, const void* X, const int32_t* x_r
             dim3 grid(cdiv(N, WG_TILE) * cdiv(K, WG_TILE), S);
             const bool fast = x_rows == nullptr && (long long)M * N * 2 < 0x7fffffffLL && (long long)M * K * 2 < 0x7fffffffLL &&
                               ((reinterpret_cast<uintptr_t>(dY) | reinterpret_cast<uintptr_t>(X)) & 15) == 0;
-            if (fast)
-                hipLaunchKernelGGL(gemm_tn_fast_kernel<3>, dim3(grid.x * grid.y), dim3(GT), 3 * 2 * 32 * 256, s, (const bf16_t*)dY, (const bf16_t*)X, target,
+            static const char* wenv = getenv("STAR_AMD_WGRAD_WAVES");
+            // 8 waves (2 x 4, a wave owns 64 x 32 of the tile, ~2 waves per SIMD hide each other's LDS / barrier latency): alone 10-20 %
+            // faster than 4 waves (fc1 110 -> 97.5 us, proj 59.5 -> 48.8, decoder fc1 71.5 -> 58); inside the step the launches get
+            // 9 % shorter and the step time stays (11.66 ms both ways).  STAR_AMD_WGRAD_WAVES=4 selects the 4-wave kernel (A/B).
+            if (fast && !(wenv && wenv[0] == '4'))
+                hipLaunchKernelGGL((gemm_tn_fast_kernel<3, 8>), dim3(grid.x * grid.y), dim3(512), 3 * 2 * 32 * 256, s, (const bf16_t*)dY, (const bf16_t*)X, target,
+                                   db ? part : (float*)nullptr, M, N, K, mp);
+            else if (fast)
+                hipLaunchKernelGGL((gemm_tn_fast_kernel<3, 4>), dim3(grid.x * grid.y), dim3(GT), 3 * 2 * 32 * 256, s, (const bf16_t*)dY, (const bf16_t*)X, target,
                                    db ? part : (float*)nullptr, M, N, K, mp);
             else
                 hipLaunchKernelGGL(gemm_tn_bf16_kernel, grid, dim3(GT), 4 * WG_BKM * 256, s, (const bf16_t*)dY, (const bf16_t*)X, x_rows, target,
