@@ -681,9 +681,10 @@ static void launch_nt_fast_epi(const StarGemm* g, hipStream_t s) {
 // whole line (48 us); a 15-stage ring, vmcnt up to 60 (61 us at 64-row tiles); 64-row tiles (52 us).  With the MFMAs
 // compiled out the kernel still takes 36 us (one producer wave lands a 1 KiB piece every ~94 cycles = 11 B/clk/CU), with
 // the stores compiled out 37 us: the remaining lever is hiding the epilogue of tile t in the MFMA gaps of tile t + 1.
-template <int NK, int WN, int RB>
+template <int NK, int WN, int RB, int EPI>
 __global__ __launch_bounds__((WN + 1) * 64) __attribute__((amdgpu_waves_per_eu(1, 1)))
 void gemm_nt_wreg_kernel(const StarGemm g, int row_tiles) {
+    static_assert(EPI == EPI_LINEAR || EPI == EPI_MULAUX, "epilogues of the W-in-registers kernel");
     constexpr int BM = RB * 16, NP = RB, NST = 8, PF = NST - 2, STAGE = BM * 64, K = NK * 32;   // a deeper ring (vmcnt up to 60) measured slower
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int N = g.N;
@@ -757,9 +758,21 @@ void gemm_nt_wreg_kernel(const StarGemm g, int row_tiles) {
         bias16[4 * a] = t.x; bias16[4 * a + 1] = t.y; bias16[4 * a + 2] = t.z; bias16[4 * a + 3] = t.w;
     }
     bf16_t* out_lp = (bf16_t*)g.out_lp;
+    const bf16_t* aux = (const bf16_t*)g.aux;     // EPI_MULAUX: the factor rows
     int st = 0;
     for (int tile = 0; tile < my_tiles; ++tile) {
         const int m_blk = (j0 + tile * J) * BM;
+        // EPI_MULAUX: the tile's factor rows are requested before its MFMA chain (consumer waves have no other loads in flight: the
+        // LDS-DMA ring belongs to the producer wave), 8 values per (row group, column half)
+        uint4 pa[EPI == EPI_MULAUX ? RB : 1][2];
+        if constexpr (EPI == EPI_MULAUX) {
+#pragma unroll
+            for (int b = 0; b < RB; ++b) {
+                const bf16_t* arow = aux + (size_t)(m_blk + b * 16 + lr) * N;
+                pa[b][0] = *reinterpret_cast<const uint4*>(arow + roff[0]);
+                pa[b][1] = *reinterpret_cast<const uint4*>(arow + roff[2]);
+            }
+        }
         f32x4_t acc[4][RB];
 #pragma unroll
         for (int a = 0; a < 4; ++a)
@@ -799,6 +812,14 @@ void gemm_nt_wreg_kernel(const StarGemm g, int row_tiles) {
                 float v[8];
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] = acc[2 * h + (e >> 2)][b][e & 3] + bias16[8 * h + e];
+                if constexpr (EPI == EPI_MULAUX) {
+                    const unsigned w[4] = {pa[b][h].x, pa[b][h].y, pa[b][h].z, pa[b][h].w};
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        v[2 * k] *= __uint_as_float(w[k] << 16);
+                        v[2 * k + 1] *= __uint_as_float(w[k] & 0xffff0000u);
+                    }
+                }
                 *reinterpret_cast<uint4*>(row + roff[2 * h]) = make_uint4(pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]), pack_bf16(v[4], v[5]), pack_bf16(v[6], v[7]));
             }
         }
@@ -808,11 +829,20 @@ void gemm_nt_wreg_kernel(const StarGemm g, int row_tiles) {
 // eligibility + launch of the W-in-registers kernel; returns false when the shape / epilogue is not covered.
 // Measured alone on MI355X at M = 40 960, K = 384 against the 256 x 128 tile: N = 1152 47.5 vs 53.8 us, N = 1536 62.5 vs
 // 74.2 us, N = 384 23.2 vs 22.0 us -> used from N = 1152 up.  STAR_AMD_GEMM_WREG=0 turns it off, =1 takes every eligible shape.
+// Round 2: the x-aux input gradient of fc2 (K = 384, N = 1536: `du = (g W2) * gelu'`) runs here too (EPI_MULAUX: the factor rows of a tile
+// are requested before its MFMA chain): 104 -> 84 us alone, 12.00 -> 11.90 ms per step.  The fc1 + GELU forward does NOT: with one
+// wave per SIMD the GELU arithmetic is serial behind the MFMAs (115 us against 103 for the 256 x 256 tile).
+template <int EPI>
 static bool launch_nt_wreg(const StarGemm* g, hipStream_t s) {
     static const char* env = getenv("STAR_AMD_GEMM_WREG");
     if (env && env[0] == '0') return false;
+    if (EPI != EPI_LINEAR) {
+        static const char* env2 = getenv("STAR_AMD_GEMM_WREG_EPI");     // 0: the x-aux epilogue stays on the tiled kernel (A/B)
+        if (env2 && env2[0] == '0') return false;
+    }
     constexpr int RB = 8, BM = RB * 16, LDS = 8 * BM * 64;
     if (g->K != 384 || g->N % 192 != 0 || g->M % BM != 0 || g->a_rows || g->c_rows || g->out_f32 || !g->out_lp) return false;
+    if (EPI == EPI_MULAUX && !g->aux) return false;
     if (!(env && env[0] == '1') && g->N < 1152) return false;
     if ((long long)g->M * g->K * 2 >= 0x7fffffffLL) return false;
     const int panels = g->N / 192;
@@ -823,21 +853,23 @@ static bool launch_nt_wreg(const StarGemm* g, hipStream_t s) {
     const int grid = cus / l * l;
     static bool attr = false;
     if (!attr) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_wreg_kernel<12, 3, RB>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_wreg_kernel<12, 3, RB, EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         attr = true;
     }
-    hipLaunchKernelGGL((gemm_nt_wreg_kernel<12, 3, RB>), dim3(grid), dim3(256), (size_t)LDS, s, *g, g->M / BM);
+    hipLaunchKernelGGL((gemm_nt_wreg_kernel<12, 3, RB, EPI>), dim3(grid), dim3(256), (size_t)LDS, s, *g, g->M / BM);
     return true;
 }
 
 template <int NST>
 static int launch_nt_fast(const StarGemm* g, hipStream_t s) {
     const bool plain = !g->res2 && !g->aux && !g->pre && g->act == STAR_ACT_NONE;
-    if (plain && !g->res && launch_nt_wreg(g, s)) return 0;
+    if (plain && !g->res && launch_nt_wreg<EPI_LINEAR>(g, s)) return 0;
     if (plain && !g->res) launch_nt_fast_epi<NST, EPI_LINEAR>(g, s);
     else if (plain) launch_nt_fast_epi<NST, EPI_RES>(g, s);
     else if (g->act == STAR_ACT_GELU && (!g->pre || (g->flags & STAR_GEMM_PRE_IS_GRAD)) && !g->aux && !g->res && !g->res2) launch_nt_fast_epi<NST, EPI_GELU_GRAD>(g, s);
-    else if (g->act == STAR_ACT_MULAUX && !g->bias && !g->res && !g->res2 && !g->pre) launch_nt_fast_epi<NST, EPI_MULAUX>(g, s);
+    else if (g->act == STAR_ACT_MULAUX && !g->bias && !g->res && !g->res2 && !g->pre) {
+        if (!launch_nt_wreg<EPI_MULAUX>(g, s)) launch_nt_fast_epi<NST, EPI_MULAUX>(g, s);
+    }
     else launch_nt_fast_epi<NST, EPI_GENERIC>(g, s);
     return 0;
 }

@@ -648,6 +648,11 @@ def test_gemm_w_in_registers_path(M, N):
     eye[idx, idx % K] = 1
     lp, _, _ = ops.gemm(eye, w, want_lp=True, want_f32=False)
     assert torch.equal(lp, w.t()[idx % K])
+    # the same kernel with the x-aux epilogue of fc2's input gradient
+    from star_amd._lib import ACT_MULAUX
+    aux = _rand_lp((M, N), g, 0)
+    du, _, _ = ops.gemm(a, w, act=ACT_MULAUX, aux=aux)
+    torch.testing.assert_close(du.double(), ref * aux.double(), **_tol(0))
 
 
 def test_layernorm_deferred_folds_in_one_launch_are_bit_identical():
