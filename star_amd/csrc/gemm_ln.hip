@@ -280,6 +280,9 @@ extern "C" int star_gemm_res_ln(const void* A, const void* W, const float* bias,
     STAR_CHECK(A && W && bias && res && x_out && gamma && beta && h, "star_gemm_res_ln: null pointer");
     STAR_CHECK(star_gemm_res_ln_supported(N, K, dt), "star_gemm_res_ln: no kernel for N=%d K=%d dt=%d (bf16, N = 256 or 384, K %% 32 == 0)", N, K, dt);
     STAR_CHECK(M >= 0 && (long long)M * K * 2 < 0x7fffffffLL, "star_gemm_res_ln: M=%d K=%d: the A operand must stay below 2 GiB", M, K);
+    STAR_CHECK(((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(W) | reinterpret_cast<uintptr_t>(bias) | reinterpret_cast<uintptr_t>(res) |
+                 reinterpret_cast<uintptr_t>(x_out) | reinterpret_cast<uintptr_t>(gamma) | reinterpret_cast<uintptr_t>(beta) |
+                 reinterpret_cast<uintptr_t>(h)) & 15) == 0, "star_gemm_res_ln: every operand must be 16-byte aligned");
     if (M == 0) return 0;
     const char* env = getenv("STAR_AMD_GEMM_LN_GEO");   // read per call (tests walk the geometries in one process)
     int geo = env ? atoi(env) : res_ln_geometry(M, N, K);
