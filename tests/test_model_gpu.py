@@ -246,6 +246,38 @@ def test_full_size_model_with_the_one_kernel_mlp_matches_the_two_gemm_path(monke
     assert rel < 2e-2, float(rel)
 
 
+@pytest.mark.parametrize("B,A", [(1, 3), (8, 5)])
+def test_full_size_model_with_layernorm_in_the_linear_matches_the_two_launch_path(B, A, monkeypatch):
+    """STAR_AMD_GEMM_LN (star_gemm_res_ln: proj / fc2 + residual + the LayerNorm behind them in one launch) against the two-launch
+    path on the benchmarked model, bf16, training.  3 frames: only proj takes the one-kernel path (96-row tiles); 40 frames (the
+    benchmarked batch): proj and fc2 do (192-row tiles).  Same loss to 1e-4, decisions identical but for near-ties, gradients
+    within the bf16 noise of the two paths (the float32 residual stream differs only by summation order)."""
+    from star_amd import engine
+    from star_amd.models import multiagent_mae as mm
+    from star_amd.synthetic import make_batch
+
+    T = 1
+    data = make_batch(B, A, T, seed=17, occupancy=0.05, device=DEV)
+    noise = torch.rand(A * B, 1024, generator=torch.Generator().manual_seed(6)).to(DEV)
+    outs = []
+    for fused in (False, True):
+        monkeypatch.setattr(engine, "_GEMM_LN", fused)
+        torch.manual_seed(0)
+        model = mm.amortized_ind_patch8_light(time_stamp=T, mask_method="complement").to(DEV).set_compute_dtype("bf16")
+        model.train()
+        model._noise_override = noise
+        bev = data["bev_seq"].squeeze(1).permute(0, 3, 1, 2)
+        loss, result, latent, ind = model(bev, data["bev_seq_next"], bev, data["trans_matrices"], data["num_agent"], B)
+        loss.backward()
+        g = torch.cat([p.grad.reshape(-1) for p in model.parameters() if p.grad is not None])
+        outs.append((loss.item(), ind.clone(), g.clone()))
+        del model, loss, result, latent
+    assert abs(outs[0][0] - outs[1][0]) < 1e-4 * max(1.0, abs(outs[0][0]))
+    assert (outs[0][1] != outs[1][1]).float().mean().item() < 2e-3
+    rel = (outs[0][2] - outs[1][2]).norm() / outs[0][2].norm()
+    assert rel < 2e-2, float(rel)
+
+
 def test_full_size_light_model_against_oracle():
     """The benchmarked model (amortized_ind_patch8_light, 256 x 256 x 13, L = 1024 tokens, hd 32 / 16) on one 3-agent scene
     with T = 2: HIP fp32 mode against the CPU oracle on the same weights, inputs and mask noise -- the size at which
