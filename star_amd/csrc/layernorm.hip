@@ -7,7 +7,7 @@
 
 #define LN_THREADS 256
 #define LN_MAXV 8          // float4 per lane: D <= 64*4*8 = 2048
-#define LN_BWD_BLOCKS 768   // partial dgamma/dbeta rows = workgroups: three per CU (A/B inside the step: 768 beats 512, 1024 and 2048 by 0.3-0.5 %)
+#define LN_BWD_BLOCKS 768   // partial dgamma/dbeta rows = workgroups: three per CU (A/B inside the step: 768 beats 512, 1024 and 2048 by 0.3-0.5 %; final round-2 build: 768 11.89-11.91 ms, 1024 11.89-11.92, 512 12.02-12.06)
 #define LN_BWD_THREADS 512  // 8 waves: 1024 blocks put 8 waves on every SIMD, each with one row's loads in flight
 
 template <typename T, int NV>
