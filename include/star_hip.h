@@ -149,6 +149,27 @@ int star_gemm(const StarGemm* g, void* stream);
 int64_t star_gemm_wgrad_ws(int M, int N, int K);
 int star_gemm_wgrad(const void* dY, const void* X, const int32_t* x_rows, float* dW, float* db, float* ws,
                     int M, int N, int K, int dt, void* stream);
+/* Several weight gradients in ONE launch (the four Linears of a timm Block, mae_base.py:279-281,308-310, whose autograd
+ * backward the reference runs as four separate addmm's): job j computes dW_j [N_j, K_j] = dY_j^T X_j and, when db_j is given,
+ * db_j = column sums of dY_j, exactly as star_gemm_wgrad does for one product (bf16 operands, N and K multiples of 8, no row
+ * gather, 16-byte aligned pointers, at most 2 GiB per operand).  Every job is cut into row splits and 128 x 128 or 384 x 128 output
+ * tiles by ITS OWN shape only -- so its result has the same bits whatever it shares a launch with -- few enough that a block's
+ * four products fill the chip together; the split partial tiles are folded inside the kernel in a fixed order (bitwise
+ * reproducible results, no atomics on data).  Jobs of the two tile shapes go out as two launches.  ws: float32
+ * [star_gemm_wgrad_group_ws(...)] (-1: the jobs are not eligible, see star_last_error); its first 4 KiB are ticket counters that
+ * MUST be zero on entry and are zero again when the call has run, so one zero-initialised buffer serves every call -- calls
+ * sharing a workspace must be ordered on one stream. */
+#define STAR_WGRAD_GROUP_MAX 8
+typedef struct StarWgradJob {
+    const void* dY;   /* [M, N] bf16 */
+    const void* X;    /* [M, K] bf16 */
+    float* dW;        /* [N, K] float32, written */
+    float* db;        /* optional [N] float32, written */
+    int32_t M, N, K;
+    int32_t reserved;
+} StarWgradJob;
+int64_t star_gemm_wgrad_group_ws(const StarWgradJob* jobs, int njobs, int dt);
+int star_gemm_wgrad_group(const StarWgradJob* jobs, int njobs, float* ws, int64_t ws_floats, int dt, void* stream);
 
 /* ---- K3 + K2: the Linear that closes a residual branch and the LayerNorm that reads its result, one launch -------------
  * Replaces, in timm 0.3.2 Block.forward (ctor mae_base.py:279-281,308-310), `x = x + proj(...)` / `x = x + fc2(...)` together

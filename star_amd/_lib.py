@@ -31,6 +31,12 @@ class StarGemm(C.Structure):
     ]
 
 
+class StarWgradJob(C.Structure):
+    _fields_ = [("dY", C.c_void_p), ("X", C.c_void_p), ("dW", C.c_void_p), ("db", C.c_void_p),
+                ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32), ("reserved", C.c_int32)]
+
+
+WGRAD_GROUP_MAX = 8
 _P, _I, _L, _F = C.c_void_p, C.c_int, C.c_int64, C.c_float
 _SIGS = {
     "star_version": (C.c_int, []),
@@ -48,6 +54,8 @@ _SIGS = {
     "star_gemm": (C.c_int, [C.POINTER(StarGemm), _P]),
     "star_gemm_wgrad_ws": (C.c_int64, [_I, _I, _I]),
     "star_gemm_wgrad": (C.c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "star_gemm_wgrad_group_ws": (C.c_int64, [C.POINTER(StarWgradJob), _I, _I]),
+    "star_gemm_wgrad_group": (C.c_int, [C.POINTER(StarWgradJob), _I, _P, _L, _I, _P]),
     "star_attn_fwd": (C.c_int, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "star_attn_bwd": (C.c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "star_gemm_res_ln_supported": (C.c_int, [_I, _I, _I]),

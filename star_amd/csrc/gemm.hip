@@ -652,7 +652,7 @@ static void launch_nt_fast_geo(const StarGemm* g, hipStream_t s) {
 template <int EPI>
 static int nt_geometry(const StarGemm* g) {
     static const char* env = getenv("STAR_AMD_GEMM_GEO");
-    if (env && env[0] >= '0' && env[0] <= '3') return env[0] - '0';
+    if (env && env[0] >= '0' && env[0] <= '2') return env[0] - '0';
     if ((long long)cdiv(g->M, 128) * cdiv(g->N, 128) * 2 <= star_num_cus()) return 3;   // few tiles: halve them (one-scene inference)
     if (EPI == EPI_LINEAR && (long long)cdiv(g->M, 256) * cdiv(g->N, 128) >= star_num_cus()) return 1;
     if (EPI == EPI_GELU_GRAD && g->N >= 1536 && (long long)cdiv(g->M, 256) * cdiv(g->N, 256) >= 2 * star_num_cus()) return 2;
@@ -1061,21 +1061,15 @@ __global__ __launch_bounds__(GT) void gemm_tn_bf16_kernel(const bf16_t* __restri
 // of the matrices are zero-filled by the buffer range check (splits are multiples of 32 rows, so a stage
 // never straddles two splits).  The bias gradient costs no memory traffic at all: in the k-tile-0 blocks
 // one extra MFMA per n-tile multiplies the dY fragment with an all-ones A operand (row sums on the matrix core).
+// Main loop of one 128 x 128 output tile over rows [m_begin, m_end): accumulators acc[a][b] (k block a, n block b of the wave) and,
+// with do_bias_tile, the column sums of dY in accb[b][0] (waves with wk == 0).
 template <int NST, int NWV>
-__global__ __launch_bounds__(NWV * 64) void gemm_tn_fast_kernel(const bf16_t* __restrict__ dY, const bf16_t* __restrict__ X,
-                                                          float* __restrict__ out, float* __restrict__ bias_part, int M, int N, int K,
-                                                          int m_per_split) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+__device__ __forceinline__ void tn_fast_mainloop(unsigned char* smem, const bf16_t* __restrict__ dY, const bf16_t* __restrict__ X, int M, int N,
+                                                 int K, int n_blk, int k_blk, int m_begin, int m_end, bool do_bias_tile,
+                                                 f32x4_t (&acc)[4][16 / NWV], f32x4_t (&accb)[16 / NWV]) {
     // NWV waves: 2 over k x NWV/2 over n; a wave owns 64 (k) x 128/(NWV/2) (n) of the 128 x 128 tile
     constexpr int TB = 32 * 256, STAGE = 2 * TB, PF = NST - 1, NJ = 8 / NWV, NB = 16 / NWV, RPW = 32 / NWV;
     static_assert(NWV == 4 || NWV == 8, "4 or 8 waves");
-    // XCD-aware order: all output tiles of one split read the same rows of dY and X, so a split's tiles run on ONE XCD
-    // (one L2 fetch per row block instead of one per XCD; measured 361 -> ~1x the operand bytes per launch)
-    const int tiles_n = (N + WG_TILE - 1) / WG_TILE, tiles = tiles_n * ((K + WG_TILE - 1) / WG_TILE);
-    const int work = xcd_remap(blockIdx.x, gridDim.x);
-    const int tile = work % tiles, split = work / tiles;
-    const int n_blk = (tile % tiles_n) * WG_TILE, k_blk = (tile / tiles_n) * WG_TILE;
-    const int m_begin = split * m_per_split, m_end = min(M, m_begin + m_per_split);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wk = wave & 1, wn = wave >> 1;
@@ -1103,14 +1097,13 @@ __global__ __launch_bounds__(NWV * 64) void gemm_tn_fast_kernel(const bf16_t* __
                                                      offX[j] + st_ * stepX, 0, 0, 0);
         }
     };
-    f32x4_t acc[4][NB], accb[NB];
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
         accb[b] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int a = 0; a < 4; ++a) acc[a][b] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
     }
-    const bool do_bias = bias_part != nullptr && k_blk == 0 && wk == 0;
+    const bool do_bias = do_bias_tile && wk == 0;
     const short one = (short)0x3F80;
     const short8_t ones = (short8_t){one, one, one, one, one, one, one, one};
     const int r0 = lg * 8 + lq;
@@ -1140,32 +1133,38 @@ __global__ __launch_bounds__(NWV * 64) void gemm_tn_fast_kernel(const bf16_t* __
         if (st + PF < nsteps) issue(st + PF);
         // transposed reads as inline asm (common.h): the builtin would make the compiler drain the DMA ring (vmcnt(0))
         const unsigned sb = lds_base + (st % NST) * STAGE;
+        // fragment reads in the order the MFMAs consume them (dY blocks first, then one X block per MFMA row), each MFMA row behind a
+        // COUNTED lgkmcnt: ds_read_b64_tr_b16 at two waves per SIMD reaches a fraction of the LDS rate when every stage drains to
+        // lgkmcnt(0) before its first MFMA (measured: no gain by itself at 128 x 128 -- the stage is bound by its LDS-DMA issue and barrier, see tn_wide_mainloop)
         short4_t xl[4], xh[4], yl[NB], yh[NB];
-#pragma unroll
-        for (int a = 0; a < 4; ++a) {
-            xl[a] = tr16<0>(sb + ax[a]);
-            xh[a] = tr16<0>(sb + axh[a]);
-        }
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
             yl[b] = tr16<0>(sb + ay[b]);
             yh[b] = tr16<0>(sb + ayh[b]);
         }
-        asm volatile("s_waitcnt lgkmcnt(0)"
-                     : "+v"(xl[0]), "+v"(xl[1]), "+v"(xl[2]), "+v"(xl[3]), "+v"(xh[0]), "+v"(xh[1]), "+v"(xh[2]), "+v"(xh[3]));
-        if constexpr (NB == 4) asm volatile("" : "+v"(yl[0]), "+v"(yl[1]), "+v"(yl[2]), "+v"(yl[3]), "+v"(yh[0]), "+v"(yh[1]), "+v"(yh[2]), "+v"(yh[3]));
-        else asm volatile("" : "+v"(yl[0]), "+v"(yl[1]), "+v"(yh[0]), "+v"(yh[1]));
-        short8_t fx[4], fy[NB];
 #pragma unroll
-        for (int a = 0; a < 4; ++a) fx[a] = (short8_t){xl[a][0], xl[a][1], xl[a][2], xl[a][3], xh[a][0], xh[a][1], xh[a][2], xh[a][3]};
+        for (int a = 0; a < 4; ++a) {
+            xl[a] = tr16<0>(sb + ax[a]);
+            xh[a] = tr16<0>(sb + axh[a]);
+        }
+        short8_t fy[NB];
 #pragma unroll
-        for (int b = 0; b < NB; ++b) fy[b] = (short8_t){yl[b][0], yl[b][1], yl[b][2], yl[b][3], yh[b][0], yh[b][1], yh[b][2], yh[b][3]};
+        for (int a = 0; a < 4; ++a) {
+            if (a == 0) {
+                if constexpr (NB == 4) asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(yl[0]), "+v"(yl[1]), "+v"(yl[2]), "+v"(yl[3]), "+v"(yh[0]), "+v"(yh[1]), "+v"(yh[2]), "+v"(yh[3]), "+v"(xl[0]), "+v"(xh[0]));
+                else asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(yl[0]), "+v"(yl[1]), "+v"(yh[0]), "+v"(yh[1]), "+v"(xl[0]), "+v"(xh[0]));
 #pragma unroll
-        for (int a = 0; a < 4; ++a)
+                for (int b = 0; b < NB; ++b) fy[b] = (short8_t){yl[b][0], yl[b][1], yl[b][2], yl[b][3], yh[b][0], yh[b][1], yh[b][2], yh[b][3]};
+            } else if (a == 1) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(xl[1]), "+v"(xh[1]));
+            else if (a == 2) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(xl[2]), "+v"(xh[2]));
+            else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(xl[3]), "+v"(xh[3]));
+            const short8_t fxa = (short8_t){xl[a][0], xl[a][1], xl[a][2], xl[a][3], xh[a][0], xh[a][1], xh[a][2], xh[a][3]};
 #pragma unroll
             for (int b = 0; b < NB; ++b)
-                acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, fx[a]), __builtin_bit_cast(bf16x8_t, fy[b]),
+                acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, fxa), __builtin_bit_cast(bf16x8_t, fy[b]),
                                                                     acc[a][b], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);      // keeps the next row's wait behind this row's MFMAs (asm waits are free to move otherwise)
+        }
         if (do_bias) {
 #pragma unroll
             for (int b = 0; b < NB; ++b)
@@ -1173,7 +1172,28 @@ __global__ __launch_bounds__(NWV * 64) void gemm_tn_fast_kernel(const bf16_t* __
                                                                   accb[b], 0, 0, 0);
         }
     }
-    if (do_bias && lg == 0) {
+}
+
+template <int NST, int NWV>
+__global__ __launch_bounds__(NWV * 64) void gemm_tn_fast_kernel(const bf16_t* __restrict__ dY, const bf16_t* __restrict__ X,
+                                                          float* __restrict__ out, float* __restrict__ bias_part, int M, int N, int K,
+                                                          int m_per_split) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int NB = 16 / NWV;
+    // XCD-aware order: all output tiles of one split read the same rows of dY and X, so a split's tiles run on ONE XCD
+    // (one L2 fetch per row block instead of one per XCD; measured 361 -> ~1x the operand bytes per launch)
+    const int tiles_n = (N + WG_TILE - 1) / WG_TILE, tiles = tiles_n * ((K + WG_TILE - 1) / WG_TILE);
+    const int work = xcd_remap(blockIdx.x, gridDim.x);
+    const int tile = work % tiles, split = work / tiles;
+    const int n_blk = (tile % tiles_n) * WG_TILE, k_blk = (tile / tiles_n) * WG_TILE;
+    const int m_begin = split * m_per_split, m_end = min(M, m_begin + m_per_split);
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wk = wave & 1, wn = wave >> 1, lg = lane >> 4;
+    f32x4_t acc[4][NB], accb[NB];
+    const bool do_bias_tile = bias_part != nullptr && k_blk == 0;
+    tn_fast_mainloop<NST, NWV>(smem, dY, X, M, N, K, n_blk, k_blk, m_begin, m_end, do_bias_tile, acc, accb);
+    if (do_bias_tile && wk == 0 && lg == 0) {
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
             const int n = n_blk + wn * (NB * 16) + b * 16 + (lane & 15);
@@ -1188,6 +1208,259 @@ __global__ __launch_bounds__(NWV * 64) void gemm_tn_fast_kernel(const bf16_t* __
 #pragma unroll
         for (int a = 0; a < 4; ++a) {
             const int k0 = k_blk + wk * 64 + a * 16 + lg * 4;
+            if (k0 >= K) continue;
+            *reinterpret_cast<float4*>(o + (size_t)n * K + k0) = make_float4(acc[a][b][0], acc[a][b][1], acc[a][b][2], acc[a][b][3]);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// Grouped weight gradients: up to STAR_WGRAD_GROUP_MAX products dW_j = dY_j^T X_j in ONE launch (a transformer block's four
+// Linears are 108 output tiles of 128 x 128 at D = 384: with a common split-M of 2-3 they fill the chip, where each product
+// launched alone needs 8-28 splits and as many float32 slabs).  The split-M partial tiles are folded IN the kernel: every
+// workgroup publishes its tile (write-through stores, agent-scope release), takes a ticket on the tile's counter, and the
+// workgroup that draws the last ticket adds the S partial tiles in split order 0..S-1 -- a fixed order, whoever arrives last,
+// so the gradients stay bitwise reproducible without atomics on the data -- and writes dW / db.  The counters return to zero.
+// Work order: split-major, then job, then the tile walk with the SHORTER tile dimension fastest; xcd_remap gives every XCD a
+// contiguous run of it, i.e. a near-rectangular set of tiles of one split, whose dY / X row blocks its L2 fetches once.
+struct TnGroupArgs {
+    const bf16_t* dY[STAR_WGRAD_GROUP_MAX];
+    const bf16_t* X[STAR_WGRAD_GROUP_MAX];
+    float* dW[STAR_WGRAD_GROUP_MAX];
+    float* db[STAR_WGRAD_GROUP_MAX];
+    int M[STAR_WGRAD_GROUP_MAX], N[STAR_WGRAD_GROUP_MAX], K[STAR_WGRAD_GROUP_MAX], mper[STAR_WGRAD_GROUP_MAX], S[STAR_WGRAD_GROUP_MAX];
+    int tiles_n[STAR_WGRAD_GROUP_MAX], tiles_k[STAR_WGRAD_GROUP_MAX], bias0[STAR_WGRAD_GROUP_MAX];
+    int tile0[STAR_WGRAD_GROUP_MAX + 1];     // first tile (= ticket counter) of job j
+    int work0[STAR_WGRAD_GROUP_MAX + 1];     // first work item (= partial-tile slot) of job j: tiles x splits, job-major, split, tile
+    int njobs, bias_ld;
+    float* slabs;      // [work item][TK x TN] as the accumulators lie
+    float* bpart;      // [split][bias_ld]
+    int* counters;     // [tiles], zero between launches
+};
+#define TN_GROUP_COUNTERS 1024   // counter words at the head of the workspace (4 KiB)
+
+// write-through stores (sc0 sc1: nothing stays dirty in the XCD's L2) as buffer-store builtins, NOT inline asm: a 16-byte VMEM store
+// followed by a VALU write of its data registers needs two wait states that the compiler only inserts for stores it can see (an asm
+// form lost one accumulator of wave 0 exactly that way)
+#define STAR_CPOL_SC0_SC1 17   // cache-policy bits of the buffer builtins on gfx940+: 1 = sc0, 2 = nt, 16 = sc1
+__device__ __forceinline__ void st_wt16(__amdgpu_buffer_rsrc_t rs, unsigned byte_off, f32x4_t v) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, v), rs, byte_off, 0, STAR_CPOL_SC0_SC1);
+}
+__device__ __forceinline__ void st_wt4(__amdgpu_buffer_rsrc_t rs, unsigned byte_off, float v) {
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs, byte_off, 0, STAR_CPOL_SC0_SC1);
+}
+
+// Main loop of the grouped kernel: 8 waves as WKW (k) x 8/WKW (n); a wave owns AK x BN blocks of 16 x 16, so the tile is
+// TK = 16 AK WKW by TN = 16 BN (8/WKW).  A stage (32 rows of m) is a set of 128-column PANELS, each laid out exactly like one
+// operand tile of gemm_tn_fast_kernel ([32 rows][256 B], 32-byte slots XOR-swizzled): TN/128 panels of dY, then TK/128 of X.
+// Why wider tiles than 128 x 128: an LDS-DMA piece (1 KiB) costs the issuing wave ~60-190 cycles, as much as the 4 MFMAs it
+// feeds at 128 x 128; at 384 x 128 a piece feeds 6, at 256 x 256 8, and the fragment reads per MFMA drop from 1.5 to 0.8 / 0.75.
+// Fragment reads are issued for the whole stage and every MFMA row waits on a COUNTED lgkmcnt; rows r0 and r0 + 4 of a
+// fragment share their swizzle (r0 = 8 lg + lq, lq < 4), so the second read is the first plus offset:1024.
+template <int OFF> __device__ __forceinline__ star_short4_t tr16v(unsigned addr) { return tr16<OFF>(addr); }
+
+template <int NST, int WKW, int AK, int BN>
+__device__ __forceinline__ void tn_wide_mainloop(unsigned char* smem, const bf16_t* __restrict__ dY, const bf16_t* __restrict__ X, int M, int N,
+                                                 int K, int n_blk, int k_blk, int m_begin, int m_end, bool do_bias_tile,
+                                                 f32x4_t (&acc)[AK][BN], f32x4_t (&accb)[BN]) {
+    constexpr int WNW = 8 / WKW, TK = 16 * AK * WKW, TN = 16 * BN * WNW, PY = TN / 128, PX = TK / 128, NP = PY + PX;
+    constexpr int PANEL = 32 * 256, STAGE = NP * PANEL, PF = NST - 1;
+    static_assert(TK % 128 == 0 && TN % 128 == 0, "tile sides are multiples of the 128-column panel");
+    static_assert(2 * (AK - 1) <= 15 && NP * PF <= 63, "counted waits");
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wk = wave % WKW, wn = wave / WKW;
+    const int lg = lane >> 4, lq = (lane & 15) >> 2, lp = lane & 3;
+
+    __amdgpu_buffer_rsrc_t rsY = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(dY), 0, (unsigned)((long long)M * N * 2), 0x00020000);
+    __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(X), 0, (unsigned)((long long)M * K * 2), 0x00020000);
+    // every wave fills rows 4 wave .. 4 wave + 3 of every panel: one 1 KiB piece per panel and stage
+    unsigned off[NP];
+    {
+        const int r = wave * 4 + (lane >> 4);
+        const int pc = lane & 15;
+        const int col = (((pc >> 1) ^ tn_swz(r)) << 4) + ((pc & 1) << 3);
+#pragma unroll
+        for (int q = 0; q < PY; ++q) off[q] = n_blk + q * 128 + col < N ? (unsigned)(((long long)(m_begin + r) * N + n_blk + q * 128 + col) * 2) : 0x80000000u;
+#pragma unroll
+        for (int q = 0; q < PX; ++q) off[PY + q] = k_blk + q * 128 + col < K ? (unsigned)(((long long)(m_begin + r) * K + k_blk + q * 128 + col) * 2) : 0x80000000u;
+    }
+    const unsigned stepY = 32u * N * 2, stepX = 32u * K * 2;
+    auto issue = [&](int st_) {
+        unsigned char* sb = smem + (st_ % NST) * STAGE + wave * 4 * 256;
+#pragma unroll
+        for (int q = 0; q < PY; ++q)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsY, (__attribute__((address_space(3))) void*)(sb + q * PANEL), 16, off[q] + st_ * stepY, 0, 0, 0);
+#pragma unroll
+        for (int q = 0; q < PX; ++q)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, (__attribute__((address_space(3))) void*)(sb + (PY + q) * PANEL), 16, off[PY + q] + st_ * stepX, 0, 0, 0);
+    };
+#pragma unroll
+    for (int b = 0; b < BN; ++b) {
+        accb[b] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int a = 0; a < AK; ++a) acc[a][b] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    }
+    const bool do_bias = do_bias_tile && wk == 0;
+    const short one = (short)0x3F80;
+    const short8_t ones = (short8_t){one, one, one, one, one, one, one, one};
+    const int r0 = lg * 8 + lq;
+    int ax[AK], ay[BN];
+#pragma unroll
+    for (int a = 0; a < AK; ++a) {
+        const int col = (wk * AK + a) * 16;
+        ax[a] = (PY + (col >> 7)) * PANEL + tn_off(r0, (col & 127) >> 4) + lp * 8;
+    }
+#pragma unroll
+    for (int b = 0; b < BN; ++b) {
+        const int col = (wn * BN + b) * 16;
+        ay[b] = (col >> 7) * PANEL + tn_off(r0, (col & 127) >> 4) + lp * 8;
+    }
+    const unsigned lds_base = lds_u32(smem);
+    const int nsteps = (m_end - m_begin + 31) / 32;
+    for (int s0 = 0; s0 < PF && s0 < nsteps; ++s0) issue(s0);
+    for (int st = 0; st < nsteps; ++st) {
+        const int rem = min(nsteps - 1 - st, PF - 1);
+        if (rem >= 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * NP <= 63 ? 3 * NP : 63) : "memory");
+        else if (rem == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NP) : "memory");
+        else if (rem == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NP) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (st + PF < nsteps) issue(st + PF);
+        const unsigned sb = lds_base + (st % NST) * STAGE;
+        short4_t xl[AK], xh[AK], yl[BN], yh[BN];
+#pragma unroll
+        for (int b = 0; b < BN; ++b) {
+            yl[b] = tr16<0>(sb + ay[b]);
+            yh[b] = tr16<1024>(sb + ay[b]);
+        }
+#pragma unroll
+        for (int a = 0; a < AK; ++a) {
+            xl[a] = tr16<0>(sb + ax[a]);
+            xh[a] = tr16<1024>(sb + ax[a]);
+        }
+        short8_t fy[BN];
+#pragma unroll
+        for (int a = 0; a < AK; ++a) {
+            // outstanding reads allowed while row a runs: the X pairs of the rows behind it
+            asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(xl[a]), "+v"(xh[a]) : "n"(2 * (AK - 1 - a)));
+            if (a == 0) {
+#pragma unroll
+                for (int b = 0; b < BN; ++b) {
+                    asm volatile("" : "+v"(yl[b]), "+v"(yh[b]));
+                    fy[b] = (short8_t){yl[b][0], yl[b][1], yl[b][2], yl[b][3], yh[b][0], yh[b][1], yh[b][2], yh[b][3]};
+                }
+            }
+            const short8_t fxa = (short8_t){xl[a][0], xl[a][1], xl[a][2], xl[a][3], xh[a][0], xh[a][1], xh[a][2], xh[a][3]};
+#pragma unroll
+            for (int b = 0; b < BN; ++b)
+                acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, fxa), __builtin_bit_cast(bf16x8_t, fy[b]),
+                                                                    acc[a][b], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);      // keeps the next row's wait behind this row's MFMAs (asm waits are free to move otherwise)
+        }
+        if (do_bias) {
+#pragma unroll
+            for (int b = 0; b < BN; ++b)
+                accb[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, ones), __builtin_bit_cast(bf16x8_t, fy[b]),
+                                                                  accb[b], 0, 0, 0);
+        }
+    }
+}
+
+template <int NST, int WKW, int AK, int BN>
+__global__ __launch_bounds__(512) void gemm_tn_group_kernel(const TnGroupArgs g) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ int s_last;
+    constexpr int WNW = 8 / WKW, TK = 16 * AK * WKW, TN = 16 * BN * WNW;
+    const int work = xcd_remap(blockIdx.x, gridDim.x);
+    int j = 0;
+    while (j + 1 < g.njobs && work >= g.work0[j + 1]) ++j;
+    const int ntile = g.tiles_n[j] * g.tiles_k[j];
+    const int split = (work - g.work0[j]) / ntile;
+    const int t = (work - g.work0[j]) - split * ntile;
+    const int tn = g.tiles_n[j], tk = g.tiles_k[j];
+    int nt, kt;
+    if (tk <= tn) { kt = t % tk; nt = t / tk; } else { nt = t % tn; kt = t / tn; }
+    const int M = g.M[j], N = g.N[j], K = g.K[j];
+    const int n_blk = nt * TN, k_blk = kt * TK;
+    const int m_begin = split * g.mper[j], m_end = min(M, m_begin + g.mper[j]);
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wk = wave % WKW, wn = wave / WKW, lg = lane >> 4;
+    float* const db = g.db[j];
+    const bool do_bias_tile = db != nullptr && k_blk == 0;
+    f32x4_t acc[AK][BN], accb[BN];
+    tn_wide_mainloop<NST, WKW, AK, BN>(smem, g.dY[j], g.X[j], M, N, K, n_blk, k_blk, m_begin, m_end, do_bias_tile, acc, accb);
+    const bool bias_lane = do_bias_tile && wk == 0 && lg == 0;
+    const int S = g.S[j];
+    const int ci = g.tile0[j] + t;
+    if (S > 1) {
+        float* slab = g.slabs + ((size_t)g.work0[j] + (size_t)t * S + split) * (TK * TN);
+        __amdgpu_buffer_rsrc_t rsS = __builtin_amdgcn_make_buffer_rsrc(slab, 0, TK * TN * 4, 0x00020000);
+#pragma unroll
+        for (int a = 0; a < AK; ++a)
+#pragma unroll
+            for (int b = 0; b < BN; ++b) st_wt16(rsS, (unsigned)((((wave * AK + a) * BN + b) * 64 + lane) << 4), acc[a][b]);
+        if (bias_lane) {
+            __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(g.bpart + (size_t)split * g.bias_ld + g.bias0[j], 0, (unsigned)(N * 4), 0x00020000);
+#pragma unroll
+            for (int b = 0; b < BN; ++b) st_wt4(rsB, (unsigned)((n_blk + wn * (BN * 16) + b * 16 + (lane & 15)) << 2), accb[b][0]);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const int old = __hip_atomic_fetch_add(g.counters + ci, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int last = old == S - 1;
+            if (last) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __hip_atomic_store(g.counters + ci, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+            }
+            s_last = last;
+        }
+        __syncthreads();
+        if (!s_last) return;
+        // the last ticket: fold the S partial tiles in split order, all of them read back (this workgroup's own one included:
+        // its accumulators are dead after the store, which keeps the kernel at the register footprint of its main loop)
+        const float* slab0 = g.slabs + ((size_t)g.work0[j] + (size_t)t * S) * (TK * TN);
+        for (int s = 0; s < S; ++s) {
+            const float* sl = slab0 + (size_t)s * (TK * TN);
+#pragma unroll
+            for (int a = 0; a < AK; ++a) {
+                f32x4_t v[BN];
+#pragma unroll
+                for (int b = 0; b < BN; ++b)
+                    v[b] = __builtin_nontemporal_load(reinterpret_cast<const f32x4_t*>(sl + ((((wave * AK + a) * BN + b) * 64 + lane) << 2)));
+#pragma unroll
+                for (int b = 0; b < BN; ++b) acc[a][b] = s == 0 ? v[b] : acc[a][b] + v[b];
+            }
+            if (bias_lane) {
+#pragma unroll
+                for (int b = 0; b < BN; ++b) {
+                    const float vb = __builtin_nontemporal_load(g.bpart + (size_t)s * g.bias_ld + g.bias0[j] + n_blk + wn * (BN * 16) + b * 16 + (lane & 15));
+                    accb[b][0] = s == 0 ? vb : accb[b][0] + vb;
+                }
+            }
+        }
+    }
+    if (bias_lane) {
+#pragma unroll
+        for (int b = 0; b < BN; ++b) {
+            const int n = n_blk + wn * (BN * 16) + b * 16 + (lane & 15);
+            if (n < N) db[n] = accb[b][0];
+        }
+    }
+    float* o = g.dW[j];
+#pragma unroll
+    for (int b = 0; b < BN; ++b) {
+        const int n = n_blk + wn * (BN * 16) + b * 16 + (lane & 15);
+        if (n >= N) continue;
+#pragma unroll
+        for (int a = 0; a < AK; ++a) {
+            const int k0 = k_blk + wk * (AK * 16) + a * 16 + lg * 4;
             if (k0 >= K) continue;
             *reinterpret_cast<float4*>(o + (size_t)n * K + k0) = make_float4(acc[a][b][0], acc[a][b][1], acc[a][b][2], acc[a][b][3]);
         }
@@ -1376,6 +1649,144 @@ extern "C" int star_gemm_wgrad(const void* dY, const void* X, const int32_t* x_r
         if (gb > 2048) gb = 2048;
         hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(gb), dim3(256), 0, s, ws, (dW && S > 1) ? dW : (float*)nullptr, n4, S, part, db, N, SB);
         STAR_LAUNCH_CHECK("star_gemm_wgrad(reduce)");
+    }
+    return 0;
+}
+
+// ---- grouped weight gradients: plan + launch -------------------------------------------------------------------
+// tile shapes of the grouped kernel: (waves along k, k blocks, n blocks per wave) -> TK x TN
+struct TnShape { int wkw, ak, bn, tk, tn; };
+static const TnShape TN_SHAPES[] = {
+    {2, 4, 2, 128, 128},     // 0: the tile of gemm_tn_fast_kernel
+    {4, 6, 4, 384, 128},     // 1: K a multiple of 384 (encoder widths 384 / 1536)
+    {4, 4, 4, 256, 128},     // 2: K a multiple of 256 (decoder widths 256 / 1024); A/B only, see wgrad_job_shape
+};    // (256 x 256 with 4 x 8 blocks per wave needs 128 accumulator registers beside 48 of fragments and spills)
+
+// Tile shape and split count are functions of the JOB alone (never of what it shares a launch with), so a gradient's bits do not
+// depend on how the caller groups its products.
+static int wgrad_job_shape(const StarWgradJob& q) {
+    static const char* env = getenv("STAR_AMD_WGRAD_TILE");     // 0..2 forces a tile shape (A/B)
+    if (env && env[0] >= '0' && env[0] <= '2') return env[0] - '0';
+    // the 384-wide tile wherever it wastes nothing: alone on the chip an encoder block's four products take 215 us against 300 with
+    // 128 x 128 tiles; the 256 x 128 tile (decoder widths) measured SLOWER than 128 x 128 (169 vs 130 us: a decoder block's 24 tiles
+    // need a split of 11, whose partial tiles cost more than the wider tile saves)
+    return (q.K % 384 == 0 && q.N % 128 == 0) ? 1 : 0;
+}
+static int wgrad_job_splits(const StarWgradJob& q, const TnShape& T) {
+    // Row splits per job: 5 (STAR_AMD_WGRAD_SPLITS overrides, A/B), whatever the job's size -- equal splits give every workgroup of a
+    // launch the same number of rows, so a block's products finish together (splits in proportion to 1 / tiles, i.e. equal workgroup
+    // counts per product, measured 289 us against 219 for an encoder block: the launch waits for the long ones).  A transformer block
+    // is 36 tiles of 384 x 128 (encoder) or 48 of 128 x 128 (decoder): 180 / 240 workgroups, 3/4 of the CUs or a little under one per
+    // CU -- beside the main backward chain that measured the same step time as 7 splits (one workgroup per CU) with less partial-tile
+    // traffic (2 x 5 x 4 bytes per weight against 14 % of the operand bytes of an encoder block).
+    static int want = -1;
+    if (want < 0) {
+        const char* e = getenv("STAR_AMD_WGRAD_SPLITS");
+        want = e ? atoi(e) : 0;
+        if (want <= 0) want = 5;
+    }
+    int S = want;
+    const int max_s = q.M / (8 * 32);                          // at least 8 reduction stages per split
+    if (S > max_s) S = max_s;
+    if (S > 32) S = 32;
+    if (S < 1) S = 1;
+    return S;
+}
+
+// plan of the launch that takes the jobs of shape `sh` (jobs of the other shape are skipped); returns the number of jobs taken
+static int wgrad_group_plan(const StarWgradJob* jobs, int njobs, int sh, TnGroupArgs* a, int64_t* ws_floats) {
+    const TnShape& T = TN_SHAPES[sh];
+    int n = 0, tiles = 0, work = 0, bias_ld = 0, max_S = 1;
+    for (int j = 0; j < njobs; ++j) {
+        const StarWgradJob& q = jobs[j];
+        if (wgrad_job_shape(q) != sh) continue;
+        a->dY[n] = (const bf16_t*)q.dY; a->X[n] = (const bf16_t*)q.X; a->dW[n] = q.dW; a->db[n] = q.db;
+        a->M[n] = q.M; a->N[n] = q.N; a->K[n] = q.K;
+        a->tiles_n[n] = cdiv(q.N, T.tn); a->tiles_k[n] = cdiv(q.K, T.tk);
+        const int S = wgrad_job_splits(q, T);
+        a->S[n] = S;
+        a->mper[n] = cdiv(cdiv(q.M, S), 32) * 32;      // the last split may come out short or empty (a zero partial tile)
+        a->tile0[n] = tiles;
+        a->work0[n] = work;
+        a->bias0[n] = bias_ld;
+        tiles += a->tiles_n[n] * a->tiles_k[n];
+        work += a->tiles_n[n] * a->tiles_k[n] * S;
+        bias_ld += cdiv(q.N, 64) * 64;
+        if (S > max_S) max_S = S;
+        ++n;
+    }
+    for (int j = n; j <= STAR_WGRAD_GROUP_MAX; ++j) { a->tile0[j] = tiles; a->work0[j] = work; }
+    a->njobs = n; a->bias_ld = bias_ld;
+    *ws_floats = n == 0 ? 0 : (int64_t)max_S * bias_ld + (int64_t)work * T.tk * T.tn;
+    return tiles;
+}
+
+static int wgrad_group_check(const StarWgradJob* jobs, int njobs, int dt) {
+    STAR_CHECK(jobs && njobs >= 1 && njobs <= STAR_WGRAD_GROUP_MAX, "star_gemm_wgrad_group: 1..%d jobs", STAR_WGRAD_GROUP_MAX);
+    STAR_CHECK(dt == STAR_BF16, "star_gemm_wgrad_group: bf16 operands only (float32 products go through star_gemm_wgrad)");
+    for (int j = 0; j < njobs; ++j) {
+        const StarWgradJob& q = jobs[j];
+        STAR_CHECK(q.dY && q.X && q.dW, "star_gemm_wgrad_group: job %d: null pointer", j);
+        STAR_CHECK(q.M > 0 && q.N > 0 && q.K > 0 && q.N % 8 == 0 && q.K % 8 == 0, "star_gemm_wgrad_group: job %d: bad shape M=%d N=%d K=%d (N, K multiples of 8)", j, q.M,
+                   q.N, q.K);
+        STAR_CHECK((long long)q.M * q.N * 2 < 0x7fffffffLL && (long long)q.M * q.K * 2 < 0x7fffffffLL, "star_gemm_wgrad_group: job %d: operand over 2 GiB", j);
+        STAR_CHECK(((reinterpret_cast<uintptr_t>(q.dY) | reinterpret_cast<uintptr_t>(q.X) | reinterpret_cast<uintptr_t>(q.dW)) & 15) == 0,
+                   "star_gemm_wgrad_group: job %d: operands must be 16-byte aligned", j);
+    }
+    return 0;
+}
+
+extern "C" int64_t star_gemm_wgrad_group_ws(const StarWgradJob* jobs, int njobs, int dt) {
+    if (wgrad_group_check(jobs, njobs, dt) != 0) return -1;
+    int64_t total = TN_GROUP_COUNTERS;
+    for (int sh = 0; sh < 3; ++sh) {
+        TnGroupArgs a;
+        int64_t n = 0;
+        const int tiles = wgrad_group_plan(jobs, njobs, sh, &a, &n);
+        if (tiles > TN_GROUP_COUNTERS) { star_set_error(-1, "star_gemm_wgrad_group: %d output tiles, at most %d per call", tiles, TN_GROUP_COUNTERS); return -1; }
+        total += (n + 3) / 4 * 4;
+    }
+    return total;
+}
+
+template <int NST, int WKW, int AK, int BN>
+static void launch_tn_group(const TnGroupArgs& a, int work, hipStream_t s) {
+    constexpr int LDS = NST * (16 * AK * WKW + 16 * BN * (8 / WKW)) / 128 * 32 * 256;
+    if (LDS > 48 * 1024)    // per launch: the attribute belongs to the current device, and the call is cheap
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_group_kernel<NST, WKW, AK, BN>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    hipLaunchKernelGGL((gemm_tn_group_kernel<NST, WKW, AK, BN>), dim3(work), dim3(512), LDS, s, a);
+}
+
+extern "C" int star_gemm_wgrad_group(const StarWgradJob* jobs, int njobs, float* ws, int64_t ws_floats, int dt, void* stream) {
+    if (int rc = wgrad_group_check(jobs, njobs, dt)) return rc;
+    const int64_t need = star_gemm_wgrad_group_ws(jobs, njobs, dt);
+    if (need < 0) return -1;
+    STAR_CHECK(ws && ws_floats >= need, "star_gemm_wgrad_group: workspace of %lld floats, %lld needed", (long long)ws_floats, (long long)need);
+    STAR_CHECK((reinterpret_cast<uintptr_t>(ws) & 15) == 0, "star_gemm_wgrad_group: workspace must be 16-byte aligned");
+    hipStream_t s = (hipStream_t)stream;
+    static const char* nst_env = getenv("STAR_AMD_WGRAD_NST");     // ring depth (A/B): 3 (default) or 4 stages
+    const bool deep = nst_env && nst_env[0] == '4';
+    float* next = ws + TN_GROUP_COUNTERS;
+    // one launch per tile shape present (a block's four products share one); the launches run one after the other on the stream
+    // and use the ticket counters in turn, their partial tiles side by side
+    for (int sh = 0; sh < 3; ++sh) {
+        TnGroupArgs a;
+        int64_t n = 0;
+        wgrad_group_plan(jobs, njobs, sh, &a, &n);
+        if (a.njobs == 0) continue;
+        int max_S = 1;
+        for (int j = 0; j < a.njobs; ++j) max_S = a.S[j] > max_S ? a.S[j] : max_S;
+        a.counters = reinterpret_cast<int*>(ws);
+        a.bpart = next;
+        a.slabs = a.bpart + (size_t)max_S * a.bias_ld;
+        next += (n + 3) / 4 * 4;
+        const int work = a.work0[a.njobs];
+        switch (sh) {
+            case 1: if (deep) launch_tn_group<4, 4, 6, 4>(a, work, s); else launch_tn_group<3, 4, 6, 4>(a, work, s); break;
+            case 2: if (deep) launch_tn_group<4, 4, 4, 4>(a, work, s); else launch_tn_group<3, 4, 4, 4>(a, work, s); break;
+            default: if (deep) launch_tn_group<4, 2, 4, 2>(a, work, s); else launch_tn_group<3, 2, 4, 2>(a, work, s); break;
+        }
+        STAR_LAUNCH_CHECK("star_gemm_wgrad_group");
     }
     return 0;
 }

@@ -305,10 +305,15 @@ _MLP_FUSED = os.environ.get("STAR_AMD_MLP_FUSED", "0") == "1"       # the block 
 _SKIP_WGRAD = os.environ.get("STAR_AMD_SKIP_WGRAD", "0") == "1"   # measurement only (wrong gradients): the backward chain without its weight-gradient GEMMs
 
 
-def _wg(grads, G, name, dy, x, x_rows=None, side=None, wait=True):
-    """weight + bias gradient of Linear `name`, written into the caller's gradient views when given."""
+def _wg(grads, G, name, dy, x, x_rows=None, side=None, wait=True, queue=None):
+    """weight + bias gradient of Linear `name`, written into the caller's gradient views when given.  queue (a _WgQueue): the
+    product waits there for the next grouped launch (star_gemm_wgrad_group) when it is eligible for one."""
     if _SKIP_WGRAD and G is not None:
         grads[name + ".weight"], grads[name + ".bias"] = G[name + ".weight"], G[name + ".bias"]
+        return
+    if queue is not None and ops.wgrad_group_eligible(dy, x, x_rows):
+        grads[name + ".weight"], grads[name + ".bias"] = queue.add(dy, x, None if G is None else G[name + ".weight"],
+                                                                   None if G is None else G[name + ".bias"])
         return
 
     def run():
@@ -316,6 +321,53 @@ def _wg(grads, G, name, dy, x, x_rows=None, side=None, wait=True):
                               db=None if G is None else G[name + ".bias"])
     dw, db = run() if side is None else side.run(run, dy, x, x_rows, wait=wait)
     grads[name + ".weight"], grads[name + ".bias"] = dw, db
+
+
+# Weight gradients of a backward pass leave in GROUPS: one launch computes up to eight of them and folds the split partials in the
+# kernel (ops.gemm_wgrad_group; tile shape and split count depend on each product alone, so the grouping never changes a bit of the
+# result).  Where the groups are cut (STAR_AMD_WGRAD_FLUSH, a comma list of points inside a block's backward):
+#   "block" (default) at the end of every block: its four products, one launch beside the next block's input-gradient GEMMs;
+#   "attn"  right before every attention backward (a block's fc2 / fc1 / proj products and the qkv product of the block before it);
+#   "fc1", "proj": after that product is queued (finer groups).
+# Measured inside one GPU call (B = 8 training step, round 3): separate launches + reduce kernels 11.52 ms (weight-gradient kernels
+# 5.3 ms of side-stream time, 90 launches); grouped "block" 11.65 ms (3.0 ms, 12 launches); "attn" 11.9 (attention backward 3.2 ->
+# 4.0 ms beside it); finer groups 11.9.  The step time does not follow the kernel time: the 384-wide kernel is denser (2 waves per
+# SIMD at 218 registers, 96 KB of LDS) and shares a CU with the main chain less well than the small one did.
+# A data-parallel wrapper (on_ready) needs a stage's gradients complete at the stage's end: the queue is flushed there too.
+WG_GROUP = os.environ.get("STAR_AMD_WGRAD_GROUP", "1") == "1"
+WG_FLUSH = os.environ.get("STAR_AMD_WGRAD_FLUSH", "block")
+_WG_FLUSH_AT = set(WG_FLUSH.split(","))       # any of: fc1 (after the fc1 product is queued), proj, attn, block
+
+
+class _WgQueue:
+    def __init__(self, side):
+        self.side, self.jobs, self.post = side, [], []
+
+    def add(self, dy, x, dw, db, post=None):
+        dev = dy.device
+        if dw is None:
+            dw = torch.empty(dy.shape[1], x.shape[1], dtype=torch.float32, device=dev)
+        if db is None:
+            db = torch.empty(dy.shape[1], dtype=torch.float32, device=dev)
+        self.jobs.append((dy, x, dw, db))
+        if post is not None:
+            self.post.append(post)
+        return dw, db
+
+    def flush(self, at=None):
+        if not self.jobs or (at is not None and at not in _WG_FLUSH_AT):
+            return
+        jobs, post = self.jobs, self.post
+        self.jobs, self.post = [], []
+
+        def run():
+            ops.gemm_wgrad_group(jobs)
+            for fn in post:
+                fn()
+        if self.side is None:
+            run()
+        else:
+            self.side.run(run, *[t for j in jobs for t in j[:2]])
 
 
 def _ln_bwd(grads, G, name, dy, x, P, mean, rstd, g_in=None, fold=None):
@@ -372,23 +424,31 @@ SIDE_EXTRA = os.environ.get("STAR_AMD_SIDE_EXTRA", "1") == "1"
 LN_FOLD_BATCH = os.environ.get("STAR_AMD_LN_FOLD_BATCH", "1") == "1"   # 0: every LayerNorm folds its dgamma / dbeta rows at once (A/B)
 
 
-def _block_bwd(g, g_lp, s, P, W, dt, grads, G=None, side=None, fold=None):
+def _block_bwd(g, g_lp, s, P, W, dt, grads, G=None, side=None, fold=None, queue=None):
     pre = s["pre"]
     heads, nb, l = s["heads"], s["nb"], s["l"]
     hd = s["x"].shape[1] // heads
     late = []
-    wg = (lambda *a, **k: late.append((a, k))) if (WG_DEFER and side is not None) else _wg
-    wg(grads, G, pre + "mlp.fc2", g_lp, s["v"], side=side)
+    wg = (lambda *a, **k: late.append((a, k))) if (WG_DEFER and side is not None and queue is None) else _wg
+    wg(grads, G, pre + "mlp.fc2", g_lp, s["v"], side=side, queue=queue)
     du, _, _ = ops.gemm(g_lp, _lin(P, W, pre + "mlp.fc2", dt, True), act=ACT_MULAUX, aux=s["u"])
-    _wg(grads, G, pre + "mlp.fc1", du, s["h2"], side=side)
+    _wg(grads, G, pre + "mlp.fc1", du, s["h2"], side=side, queue=queue)
+    if queue is not None:
+        queue.flush("fc1")
     dh2, _, _ = ops.gemm(du, _lin(P, W, pre + "mlp.fc1", dt, True))
     g1, g1_lp = _ln_bwd(grads, G, pre + "norm2", dh2, s["x_mid"], P, s["mean2"], s["rstd2"], g_in=g, fold=fold)
-    _wg(grads, G, pre + "attn.proj", g1_lp, s["a"], side=side)
+    _wg(grads, G, pre + "attn.proj", g1_lp, s["a"], side=side, queue=queue)
+    if queue is not None:
+        queue.flush("proj")
     da, _, _ = ops.gemm(g1_lp, _lin(P, W, pre + "attn.proj", dt, True))
     for a, k in late:          # the held-back fc2 weight gradient starts beside the attention backward; its operands are older than
         _wg(*a, wait=False, **k)   # the side stream's last wait (fc1 / proj above), so it needs no cross-stream wait of its own
+    if queue is not None:
+        queue.flush("attn")
     dqkv = ops.attn_bwd(s["qkv"], s["a"], da, s["lse"], nb, l, heads, hd)
-    _wg(grads, G, pre + "attn.qkv", dqkv, s["h1"], side=side)
+    _wg(grads, G, pre + "attn.qkv", dqkv, s["h1"], side=side, queue=queue)
+    if queue is not None:
+        queue.flush("block")
     dh1, _, _ = ops.gemm(dqkv, _lin(P, W, pre + "attn.qkv", dt, True))
     g0, g0_lp = _ln_bwd(grads, G, pre + "norm1", dh1, s["x"], P, s["mean1"], s["rstd1"], g_in=g1, fold=fold)
     return g0, g0_lp
@@ -534,9 +594,17 @@ def backward(cfg, P, W, dt, ctx, G=None, on_ready=None):
     fold = _LnFolds(W) if G is not None and LN_FOLD_BATCH else None      # flat gradient buffer: all LayerNorm folds in one launch at the end
     # prediction heads: weight gradient (and its row permutation back to the reference order) beside the dgrad chain
     side_x = side if SIDE_EXTRA else None
+    queue = _WgQueue(side) if WG_GROUP and dt == BF16 else None      # grouped launches (with or without a side stream)
 
-    def heads_wgrad():
-        dw, db = ops.gemm_wgrad(dlog, ctx["yd"])
+    def end_stage(k, sd):
+        if on_ready is not None:
+            if queue is not None:
+                queue.flush()
+            if sd is not None:
+                sd.join()
+            on_ready(k)
+
+    def heads_unpermute(dw, db):
         idx = head_permutation(cfg, dw.device, as_int64=True)
         V = cfg.V
         for name, lo in (("decoder_pred_free", 0), ("decoder_pred_occ", V)):     # rows back in the reference order, straight into G
@@ -545,24 +613,28 @@ def backward(cfg, P, W, dt, ctx, G=None, on_ready=None):
             gw.index_copy_(0, idx, dw[lo:lo + V])
             gb.index_copy_(0, idx, db[lo:lo + V])
             grads[name + ".weight"], grads[name + ".bias"] = gw, gb
-    if side_x is None:
+
+    def heads_wgrad():
+        heads_unpermute(*ops.gemm_wgrad(dlog, ctx["yd"]))
+    if queue is not None and ops.wgrad_group_eligible(dlog, ctx["yd"]):
+        hw = torch.empty(2 * cfg.V, Dd, dtype=torch.float32, device=dlog.device)
+        hb = torch.empty(2 * cfg.V, dtype=torch.float32, device=dlog.device)
+        queue.add(dlog, ctx["yd"], hw, hb, post=lambda: heads_unpermute(hw, hb))
+        if side is not None:
+            hw.record_stream(side.stream)
+            hb.record_stream(side.stream)
+    elif side_x is None:
         heads_wgrad()
     else:
         side_x.run(heads_wgrad, dlog, ctx["yd"])
     dyd, _, _ = ops.gemm(dlog, _heads(P, W, cfg, dt, True))
     g, g_lp = _ln_bwd(grads, G, "decoder_norm", dyd, ctx["xd"], P, ctx["mean_d"], ctx["rstd_d"], fold=fold)
     stage = 0
-    if on_ready is not None:
-        if side_x is not None:
-            side_x.join()
-        on_ready(stage)
+    end_stage(stage, side_x if queue is None else side)
     for s in reversed(save[cfg.depth:]):
-        g, g_lp = _block_bwd(g, g_lp, s, P, W, dt, grads, G, side, fold)
+        g, g_lp = _block_bwd(g, g_lp, s, P, W, dt, grads, G, side, fold, queue)
         stage += 1
-        if on_ready is not None:
-            if side is not None:
-                side.join()
-            on_ready(stage)
+        end_stage(stage, side)
     # temporal un-mixing backward: g is d/d(decoder input rows)
     if ctx["random_mode"]:
         g = ops.transpose_rows_bwd(g, ba, L, Dd)                                    # Q2 backward
@@ -576,9 +648,9 @@ def backward(cfg, P, W, dt, ctx, G=None, on_ready=None):
         if ctx["random_mode"]:
             gt[0] += gtok[0]                                                        # mask tokens carry temp_embed[0]
         _put(grads, G, "decoder_temp_embed", gt.reshape(1, T, 1, Dd))
-    _wg(grads, G, "decoder_embed", dye, ctx["z"], side=side_x)
+    _wg(grads, G, "decoder_embed", dye, ctx["z"], side=side_x, queue=queue)
     dz, _, _ = ops.gemm(dye, _lin(P, W, "decoder_embed", dt, True))
-    _wg(grads, G, "decompressor", dz, ctx["dec_in_lp"], side=side_x)
+    _wg(grads, G, "decompressor", dz, ctx["dec_in_lp"], side=side_x, queue=queue)
     if cfg.vq:
         # straight-through estimator: the decoder's gradient passes to the latent, plus the commitment term; the codebook
         # only sees the q_latent term (mae_base.py:162-166); then the compressor's ReLU
@@ -593,22 +665,16 @@ def backward(cfg, P, W, dt, ctx, G=None, on_ready=None):
     else:
         dlat, _, _ = ops.gemm(dz, _lin(P, W, "decompressor", dt, True), act=ACT_DRELU, aux=ctx["latent_lp"])
     comp_rows = None if cfg.encode_partial else ctx["src_row"]
-    _wg(grads, G, "compressor.0", dlat, ctx["y"], x_rows=comp_rows, side=side_x)
+    _wg(grads, G, "compressor.0", dlat, ctx["y"], x_rows=comp_rows, side=side_x, queue=queue)
     rows_enc = n_frames * ctx["l_enc"]
     dy, _, _ = ops.gemm(dlat, _lin(P, W, "compressor.0", dt, True), c_rows=comp_rows, out_rows=rows_enc)
     g, g_lp = _ln_bwd(grads, G, "norm", dy, ctx["x_enc"], P, ctx["mean_e"], ctx["rstd_e"], fold=fold)
     stage += 1
-    if on_ready is not None:
-        if side_x is not None:
-            side_x.join()
-        on_ready(stage)
+    end_stage(stage, side_x if queue is None else side)
     for s in reversed(save[:cfg.depth]):
-        g, g_lp = _block_bwd(g, g_lp, s, P, W, dt, grads, G, side, fold)
+        g, g_lp = _block_bwd(g, g_lp, s, P, W, dt, grads, G, side, fold, queue)
         stage += 1
-        if on_ready is not None:
-            if side is not None:
-                side.join()
-            on_ready(stage)
+        end_stage(stage, side)
     # patch embedding
     wshape = P["patch_embed.proj.weight"].shape
     wname, bname = "patch_embed.proj.weight", "patch_embed.proj.bias"
@@ -618,6 +684,8 @@ def backward(cfg, P, W, dt, ctx, G=None, on_ready=None):
         dw, _ = ops.gemm_wgrad(g_lp, ctx["a_pe"], x_rows=ctx["src_row"], want_bias=False, dw=dw_out)
         db = ops.colsum_groups(g, 1, 1, sel=ctx["src_row"], sel_nonneg=True).reshape(-1)   # padded slots carry no bias
         _put(grads, G, bname, db)
+    elif queue is not None and dw_out is not None and ops.wgrad_group_eligible(g_lp, ctx["a_pe"]):
+        dw, grads[bname] = queue.add(g_lp, ctx["a_pe"], dw_out, G[bname])       # rides with the last block's qkv product
     else:
         dw, db = ops.gemm_wgrad(g_lp, ctx["a_pe"], dw=dw_out, db=None if G is None else G[bname])
         grads[bname] = db
@@ -628,6 +696,8 @@ def backward(cfg, P, W, dt, ctx, G=None, on_ready=None):
         _put(grads, G, wname, dw)
     else:
         grads[wname] = G[wname] if G is not None else dw.reshape(wshape)
+    if queue is not None:
+        queue.flush()
     if fold is not None:
         fold.run()
     if side is not None:

@@ -227,6 +227,57 @@ def gemm_wgrad(dy, x, x_rows=None, want_bias=True, want_weight=True, dw=None, db
     return dw, db
 
 
+_WG_GROUP_WS = {}      # (device, stream) -> zero-initialised workspace of the grouped launches (ticket counters return to zero)
+
+
+def wgrad_group_eligible(dy, x, x_rows=None):
+    """can this product ride in a grouped launch (star_gemm_wgrad_group)?"""
+    m, n = dy.shape
+    k = x.shape[1]
+    return (dy.dtype == torch.bfloat16 and x_rows is None and n % 8 == 0 and k % 8 == 0 and m * max(n, k) * 2 < 0x7fffffff and
+            dy.data_ptr() % 16 == 0 and x.data_ptr() % 16 == 0)
+
+
+def gemm_wgrad_group(jobs):
+    """jobs: [(dy [M,N] bf16, x [M,K] bf16, dw float32 [N,K] or None, db float32 [N] or None / False = no bias), ...] -> [(dw, db), ...].
+    One launch for all of them (star_gemm_wgrad_group); more than WGRAD_GROUP_MAX jobs go out in several launches."""
+    out = []
+    for lo in range(0, len(jobs), L.WGRAD_GROUP_MAX):
+        part = jobs[lo:lo + L.WGRAD_GROUP_MAX]
+        arr = (L.StarWgradJob * len(part))()
+        flops = nbytes = 0.0
+        dev = part[0][0].device
+        res = []
+        for i, (dy, x, dw, db) in enumerate(part):
+            _cuda(dy, x)
+            assert dy.dtype == torch.bfloat16 and x.dtype == dy.dtype and dy.is_contiguous() and x.is_contiguous() and dy.shape[0] == x.shape[0]
+            m, n = dy.shape
+            k = x.shape[1]
+            if dw is None:
+                dw = torch.empty(n, k, dtype=torch.float32, device=dev)
+            if db is None:
+                db = torch.empty(n, dtype=torch.float32, device=dev)
+            elif db is False:
+                db = None
+            assert dw.is_contiguous() and dw.numel() == n * k and dw.dtype == torch.float32
+            assert db is None or (db.is_contiguous() and db.numel() == n and db.dtype == torch.float32)
+            arr[i] = L.StarWgradJob(p(dy), p(x), p(dw), p(db), m, n, k, 0)
+            flops += 2.0 * m * n * k
+            nbytes += float(m * (n + k) * 2 + n * k * 4)
+            res.append((dw, db))
+        need = L.lib().star_gemm_wgrad_group_ws(arr, len(part), BF16)
+        if need < 0:
+            raise RuntimeError("libstar_hip: " + L.lib().star_last_error().decode())
+        key = (dev, L.stream())
+        ws = _WG_GROUP_WS.get(key)
+        if ws is None or ws.numel() < need:
+            ws = _WG_GROUP_WS[key] = torch.zeros(max(need, 1 << 22), dtype=torch.float32, device=dev)
+        with _timed("gemm_wgrad", flops, nbytes):
+            L.check(L.lib().star_gemm_wgrad_group(arr, len(part), p(ws), ws.numel(), BF16, L.stream()))
+        out += res
+    return out
+
+
 def gemm_res_ln_supported(n, k, dt):
     return bool(L.lib().star_gemm_res_ln_supported(n, k, dt))
 

@@ -243,6 +243,69 @@ def test_gemm_wgrad(dt, M, N, K):
     torch.testing.assert_close(dw2.double() / scale, (dy.double().t() @ xz[rows.long()]) / scale, rtol=1e-4, atol=1e-4)
 
 
+def _wg_group_jobs(shapes, g, scale=1.0):
+    jobs = []
+    for M, N, K in shapes:
+        dy = (_rand_lp((M, N), g, 0).float() * scale).to(torch.bfloat16)
+        jobs.append((dy, _rand_lp((M, K), g, 0), None, None))
+    return jobs
+
+
+@pytest.mark.parametrize("shapes", [
+    [(40960, 1152, 384), (40960, 384, 384), (40960, 1536, 384), (40960, 384, 1536)],      # an encoder block: 108 tiles, split 2
+    [(10240, 768, 256), (10240, 256, 256), (10240, 1024, 256), (10240, 256, 1024)],        # a decoder block, fewer rows: split 5
+    [(5000, 1664, 256), (333, 96, 32), (4097, 384, 832)],                                  # ragged rows, partial tiles, unequal M
+    [(300, 128, 128)],                                                                     # one tile, one split: no fold at all
+])
+def test_gemm_wgrad_group(shapes):
+    """star_gemm_wgrad_group against float64, against star_gemm_wgrad, and bit for bit against itself over repeated launches that
+    reuse one workspace with DIFFERENT data in between (a stale partial tile or ticket would show) while another stream keeps
+    the chip busy (uneven load: the fold's cross-workgroup hand-off must not depend on an idle chip)."""
+    g = torch.Generator().manual_seed(len(shapes) * 7 + shapes[0][0])
+    jobs = _wg_group_jobs(shapes, g)
+    other = _wg_group_jobs(shapes, g, scale=3.0)
+    first = [(dw.clone(), db.clone()) for dw, db in ops.gemm_wgrad_group(jobs)]
+    for (dy, x, _, _), (dw, db) in zip(jobs, first):
+        scale = math.sqrt(dy.shape[0])
+        torch.testing.assert_close(dw.double() / scale, (dy.double().t() @ x.double()) / scale, rtol=1e-4, atol=1e-4)
+        torch.testing.assert_close(db.double() / scale, dy.double().sum(0) / scale, rtol=1e-4, atol=1e-4)
+        dw1, db1 = ops.gemm_wgrad(dy, x)
+        torch.testing.assert_close(dw, dw1, rtol=1e-5, atol=1e-3 * scale / 64)
+        torch.testing.assert_close(db, db1, rtol=1e-5, atol=1e-3 * scale / 64)
+    side = torch.cuda.Stream()
+    big = torch.randn(64 << 20, device=DEV)
+    for it in range(6):
+        with torch.cuda.stream(side):          # background traffic on every XCD
+            for _ in range(4):
+                big.mul_(1.0001)
+        ops.gemm_wgrad_group(other)
+        again = ops.gemm_wgrad_group(jobs)
+        for (dw, db), (dw0, db0) in zip(again, first):
+            assert torch.equal(dw, dw0) and torch.equal(db, db0), "grouped weight gradient not reproducible (launch %d)" % it
+    torch.cuda.synchronize()
+    # no bias requested for one job; caller-provided outputs
+    dy, x = jobs[0][0], jobs[0][1]
+    dw = torch.full((dy.shape[1], x.shape[1]), float("nan"), device=DEV)
+    (dw_o, db_o), = ops.gemm_wgrad_group([(dy, x, dw, False)])
+    assert db_o is None and dw_o.data_ptr() == dw.data_ptr()
+    # tile shape and split count are functions of the job alone: launched on its own (or in any other company) a product comes out
+    # with the SAME bits as inside the group
+    assert torch.equal(dw, first[0][0])
+    if len(jobs) > 2:
+        regrouped = ops.gemm_wgrad_group(jobs[2:] + jobs[:1]) + ops.gemm_wgrad_group(jobs[1:2])
+        for (dw_r, db_r), k in zip(regrouped, list(range(2, len(jobs))) + [0, 1]):
+            assert torch.equal(dw_r, first[k][0]) and torch.equal(db_r, first[k][1])
+
+
+def test_gemm_wgrad_group_rejects():
+    dy, x = torch.zeros(64, 16, device=DEV), torch.zeros(64, 16, device=DEV)      # float32 operands
+    with pytest.raises((RuntimeError, AssertionError)):
+        ops.gemm_wgrad_group([(dy, x, None, None)])
+    assert not ops.wgrad_group_eligible(dy, x)
+    b = torch.zeros(64, 16, device=DEV, dtype=torch.bfloat16)
+    assert ops.wgrad_group_eligible(b, b) and not ops.wgrad_group_eligible(b, b, x_rows=torch.zeros(64, dtype=torch.int32, device=DEV))
+
+
 def test_gemm_wgrad_asymmetric():
     M, N, K = 64, 16, 16
     dy = torch.zeros(M, N, device=DEV, dtype=torch.bfloat16)

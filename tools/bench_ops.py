@@ -70,6 +70,26 @@ def wgrad_cases():
     return rows
 
 
+def wgroup_cases():
+    """a block's four weight gradients: one grouped launch against the four separate ones."""
+    g = torch.Generator().manual_seed(0)
+    rows = []
+    for name, shapes in [("wg enc block", [(1152, 384), (384, 384), (1536, 384), (384, 1536)]),
+                         ("wg dec block", [(768, 256), (256, 256), (1024, 256), (256, 1024)]),
+                         ("wg heads+dec", [(1664, 256), (768, 256), (256, 256), (1024, 256), (256, 1024)])]:
+        jobs = []
+        for N, K in shapes:
+            jobs.append((torch.randn(M, N, generator=g).to(dev).bfloat16(), torch.randn(M, K, generator=g).to(dev).bfloat16(),
+                         torch.empty(N, K, device=dev), torch.empty(N, device=dev)))
+        fl = sum(2.0 * M * N * K for N, K in shapes)
+        byt = sum(M * (N + K) * 2 for N, K in shapes)
+        us = timeit(lambda: ops.gemm_wgrad_group(jobs))
+        rows.append((name + " grouped", 0, 0, us, fl / us / 1e6, byt / us / 1e3))
+        us = timeit(lambda: [ops.gemm_wgrad(dy, x, dw=dw, db=db) for dy, x, dw, db in jobs])
+        rows.append((name + " separate", 0, 0, us, fl / us / 1e6, byt / us / 1e3))
+    return rows
+
+
 def gemm_ln_cases():
     """residual Linear + the LayerNorm behind it: one kernel against the two launches."""
     rows = []
@@ -190,6 +210,6 @@ def vq_cases():
 if __name__ == "__main__":
     which = sys.argv[1:] or ["gemm", "wgrad", "mlp", "attn", "ln", "voxel", "vq"]
     for w in which:
-        rows = dict(gemm=gemm_cases, gemm_ln=gemm_ln_cases, wgrad=wgrad_cases, mlp=mlp_cases, attn=attn_cases, ln=ln_cases, voxel=voxel_cases, vq=vq_cases)[w]()
+        rows = dict(gemm=gemm_cases, gemm_ln=gemm_ln_cases, wgrad=wgrad_cases, wgroup=wgroup_cases, mlp=mlp_cases, attn=attn_cases, ln=ln_cases, voxel=voxel_cases, vq=vq_cases)[w]()
         for name, a, b, us, tf, gbs in rows:
             print("%-26s %5d %5d  %8.1f us  %7.1f TFLOP/s  %7.1f GB/s(or Gexp/s)" % (name, a, b, us, tf, gbs))
