@@ -38,7 +38,8 @@ def parse():
     ap.add_argument("--mask_ratio", type=float, default=0.75)
     ap.add_argument("--model", default="amortized_ind_patch8_light")
     ap.add_argument("--com", default="ind_mae", choices=["ind_mae", "vqstar"], help="vqstar: the VQ-STAR variant (Makefile sizes K=8192, E=32)")
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32", "bf16x3"],
+                    help="bf16x3 (inference only): bf16 hi/lo pairs, three bf16 MFMA products per multiply -- the float32 path's decisions")
     ap.add_argument("--mode", default="train", choices=["train", "infer"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-all", action="store_true", help="print the per-kernel-family time table to stderr")
@@ -270,7 +271,8 @@ def main():
         elapsed = tmax.item()
     if rank == 0:
         value = frames_per_step * world * args.steps / elapsed
-        peak_f = PEAK_BF16_TFLOPS if args.dtype == "bf16" else PEAK_F32_TFLOPS
+        # bf16x3: one multiply is three bf16 MFMA products, so the peak for its ALGORITHMIC flops is a third of the bf16 pipe's
+        peak_f = {"bf16": PEAK_BF16_TFLOPS, "bf16x3": round(PEAK_BF16_TFLOPS / 3, 1)}.get(args.dtype, PEAK_F32_TFLOPS)
 
         def roofline_of(tag, v, samples=None):
             """Roofline entry of one kernel family from its HIP-event times: the bound is whichever of flops/peak and

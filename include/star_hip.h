@@ -11,8 +11,9 @@
  *   - `stream` is a hipStream_t passed as void*; kernels are enqueued on it and nothing synchronises;
  *   - return value: 0 = ok, negative = error; star_last_error() returns a thread-local message;
  *   - no exception crosses the ABI; entry points are re-entrant (no global mutable state);
- *   - `dt` selects the activation storage type: STAR_BF16 (bf16 storage, fp32 accumulation) or
- *     STAR_F32 (fp32 storage and fp32 MFMA, the reference's numerics).
+ *   - `dt` selects the activation storage type: STAR_BF16 (bf16 storage, fp32 accumulation),
+ *     STAR_F32 (fp32 storage and fp32 MFMA, the reference's numerics) or, for the forward kernels,
+ *     STAR_BF16X3 (bf16 hi/lo pairs, three bf16 MFMA products per multiply: float32-grade results at bf16-pipe speed).
  */
 #ifndef STAR_HIP_H
 #define STAR_HIP_H
@@ -25,6 +26,10 @@ extern "C" {
 
 #define STAR_BF16 0
 #define STAR_F32 1
+#define STAR_BF16X3 2   /* inference-grade exactness on the bf16 matrix pipe: every activation and weight is a PAIR of bf16 values
+                           hi + lo (hi = bf16(v), lo = bf16(v - hi): 16 significant bits) stored side by side -- a row of a [R, C]
+                           matrix is [hi (C) | lo (C)], 2 C bf16 values -- and every product runs as hi*hi + lo*hi + hi*lo with
+                           float32 accumulation.  Accepted by star_layernorm_fwd, star_gemm and star_attn_fwd (forward only). */
 
 int star_version(void);
 const char* star_last_error(void);
@@ -136,6 +141,8 @@ typedef struct StarGemm {
                                    (encode_partial: the patch embedding of a zero-padded slot is a zero row) */
 #define STAR_GEMM_PRE_IS_GRAD 2 /* with ACT_GELU / ACT_RELU: `pre` receives act'(pre-activation), the factor the backward
                                    pass multiplies by (ACT_MULAUX), instead of the pre-activation itself */
+#define STAR_GEMM_A_PLAIN 4     /* dt = STAR_BF16X3 only: A is a plain bf16 matrix [*, K] whose values are exact (the 0/1 occupancy
+                                   patches): two products A * W_hi + A * W_lo instead of three */
 #define STAR_ACT_NONE 0
 #define STAR_ACT_GELU 1   /* exact erf GELU (timm Mlp act_layer=nn.GELU) */
 #define STAR_ACT_RELU 2   /* compressor ReLU (mae_base.py:284-287) */
@@ -280,7 +287,8 @@ typedef struct StarCastJob {
     int32_t dst_ld;          /* leading dimension of dst; 0 = dense (cols, or rows when transposed) */
     int32_t dst_off;         /* element offset into dst: several jobs can fill one destination */
     int32_t dst_f32;         /* != 0: this job's destination is float32 whatever dt says (bias vectors) */
-    int32_t reserved;
+    int32_t split;           /* != 0 (bf16, not transposed): write bf16 PAIRS for STAR_BF16X3 -- hi at (r, c), lo = bf16(v - hi) at
+                                (r, cols + c); dst_ld must be >= 2 * cols */
 } StarCastJob;
 int star_cast_batch(const StarCastJob* jobs_dev, int njobs, int total_tiles, int dt, void* stream);
 /* AdamW (decoupled weight decay) over one flat float32 buffer, torch.optim.AdamW semantics

@@ -12,10 +12,11 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("STAR_HIP_LIB") or os.path.join(_HERE, "libstar_hip.so")   # override: A/B builds of the kernels
 
-BF16, F32 = 0, 1
+BF16, F32, BF16X3 = 0, 1, 2     # BF16X3: bf16 hi/lo pairs, three MFMA products per multiply (forward only; include/star_hip.h)
 ACT_NONE, ACT_GELU, ACT_RELU, ACT_DGELU, ACT_DRELU, ACT_MULAUX = 0, 1, 2, 3, 4, 5
 GEMM_RES_BY_AROW = 1
 GEMM_PRE_IS_GRAD = 2
+GEMM_A_PLAIN = 4
 
 _lib = None
 
@@ -147,4 +148,9 @@ def dt_of(t):
 
 
 def torch_dtype(dt):
-    return torch.bfloat16 if dt == BF16 else torch.float32
+    return torch.float32 if dt == F32 else torch.bfloat16
+
+
+def width(dt):
+    """stored elements per logical element of an activation / weight row (2 for the hi/lo pairs of BF16X3)"""
+    return 2 if dt == BF16X3 else 1

@@ -161,13 +161,8 @@ template <int HD> __device__ __forceinline__ unsigned dma_src(int piece, int lan
     return (unsigned)(row * row_bytes + ((pc ^ ((row >> C::SH) & (C::CH - 1))) << 4));
 }
 template <int N> __device__ __forceinline__ void wait_vm() {
-    if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    else if constexpr (N == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
-    else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-    else if constexpr (N == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-    else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else if constexpr (N == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-    else static_assert(N <= 5, "wait_vm");
+    static_assert(N <= 63, "wait_vm");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 // a global load that must be complete before the DMA ring starts counting: consuming the registers here keeps the
 // compiler from re-inserting its own (conservative, full) vmcnt wait inside the loop
@@ -236,12 +231,17 @@ __device__ __forceinline__ short8_t join8(short4_t lo, short4_t hi) { return (sh
 // Forward.  Stage (ring of 3) = K image | V image | [hd 16: 2 KiB of bf16 ones].  The softmax denominator comes
 // out of the matrix pipe: a ones row block appended to V^T (hd 16: the idle MFMA rows 16..31 read the ones area;
 // hd >= 32: four in-register add chains, cheaper than an extra MFMA chain on the busy matrix pipe).
-template <int HD, int QB>
+// SPL (dt = STAR_BF16X3): q, k, v and the output are bf16 PAIRS (a row is [hi | lo], the lo plane 3 H hd -- output: H hd --
+// elements further along); S = k_hi q_hi + k_lo q_hi + k_hi q_lo, the probabilities are split the same way (p_hi = bf16(p),
+// p_lo = bf16(p - p_hi)) and O = v_hi p_hi + v_lo p_hi + v_hi p_lo: three MFMAs per product, float32-grade results.  A stage then
+// carries the lo images of K and V behind the hi ones, and the row sums stay in registers (exact float32) for every head dim.
+template <int HD, int QB, bool SPL = false>
 __global__ __launch_bounds__(AT) void attn_fwd_bf16_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
                                                            float* __restrict__ lse, int L, int H, float c) {
     using C = ACfg<HD>;
-    constexpr int NI = 2 * C::NP / 4;                           // DMA instructions per wave per tile
-    constexpr int STAGE = 2 * C::TILE + (HD == 16 ? 2048 : 0);
+    constexpr int NI = 2 * C::NP / 4 * (SPL ? 2 : 1);           // DMA instructions per wave per tile
+    constexpr int LO = 2 * C::TILE + (HD == 16 ? 2048 : 0);     // SPL: offset of the lo images inside a stage
+    constexpr int STAGE = LO * (SPL ? 2 : 1);
     constexpr int QW = 32 * QB, QBLK = 4 * QW;                  // queries per wave / per block
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     // XCD-aware work order: the row blocks of one (sequence, head) stream the same K/V (Q/dO) tiles, so they
@@ -251,13 +251,14 @@ __global__ __launch_bounds__(AT) void attn_fwd_bf16_kernel(const bf16_t* __restr
     const int rblk = work % nrb, h = (work / nrb) % H, nb = work / (nrb * H);
     const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h2 = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int64_t rs = (int64_t)3 * H * HD;
+    const int64_t rs = (int64_t)3 * H * HD * (SPL ? 2 : 1);
+    const int64_t lo_el = (int64_t)3 * H * HD;        // SPL: the lo plane of a qkv row
     const bf16_t* qb = qkv + (int64_t)nb * L * rs + h * HD;
     const int q0 = rblk * QBLK + wave * QW;   // the wave's QB query blocks of 32 rows start here
 
     // QB query blocks per wave share every K fragment and V^T fragment read from LDS, every tile DMA and barrier, and
     // give the in-order wave independent MFMA / softmax chains to interleave
-    short8_t qf[QB][C::KS];
+    short8_t qf[QB][C::KS], qfl[SPL ? QB : 1][C::KS];
 #pragma unroll
     for (int qi = 0; qi < QB; ++qi)
 #pragma unroll
@@ -265,6 +266,10 @@ __global__ __launch_bounds__(AT) void attn_fwd_bf16_kernel(const bf16_t* __restr
             const int q = q0 + qi * 32 + r;
             qf[qi][ks] = (short8_t){0, 0, 0, 0, 0, 0, 0, 0};
             if (q < L) qf[qi][ks] = *reinterpret_cast<const short8_t*>(qb + (int64_t)q * rs + ks * 16 + 8 * h2);
+            if constexpr (SPL) {
+                qfl[qi][ks] = (short8_t){0, 0, 0, 0, 0, 0, 0, 0};
+                if (q < L) qfl[qi][ks] = *reinterpret_cast<const short8_t*>(qb + (int64_t)q * rs + lo_el + ks * 16 + 8 * h2);
+            }
         }
     if constexpr (HD == 16) {
         for (int i = tid; i < 3 * 128; i += AT) *reinterpret_cast<uint4*>(smem + (i >> 7) * STAGE + 2 * C::TILE + (i & 127) * 16) =
@@ -274,16 +279,21 @@ __global__ __launch_bounds__(AT) void attn_fwd_bf16_kernel(const bf16_t* __restr
 #pragma unroll
     for (int qi = 0; qi < QB; ++qi)
 #pragma unroll
-        for (int ks = 0; ks < C::KS; ++ks) pin(qf[qi][ks]);
+        for (int ks = 0; ks < C::KS; ++ks) {
+            pin(qf[qi][ks]);
+            if constexpr (SPL) pin(qfl[qi][ks]);
+        }
 
     __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(qb), 0, (unsigned)((L * rs - h * HD) * 2), 0x00020000);
     unsigned src[NI];
     int dst[NI];
 #pragma unroll
     for (int j = 0; j < NI; ++j) {
-        const int p = wave * NI + j, isv = p >= C::NP, pp = isv ? p - C::NP : p;
-        src[j] = dma_src<HD>(pp, lane, rs * 2) + (unsigned)((1 + isv) * H * HD * 2);
-        dst[j] = isv * C::TILE + pp * 1024;
+        // pieces 0 .. 2 NP - 1: the K then the V image; SPL: pieces 2 NP .. 4 NP - 1 the same of the lo plane
+        const int p4 = wave * NI + j, islo = SPL && p4 >= 2 * C::NP, p = islo ? p4 - 2 * C::NP : p4;
+        const int isv = p >= C::NP, pp = isv ? p - C::NP : p;
+        src[j] = dma_src<HD>(pp, lane, rs * 2) + (unsigned)((1 + isv) * H * HD * 2) + (islo ? (unsigned)(lo_el * 2) : 0u);
+        dst[j] = islo * LO + isv * C::TILE + pp * 1024;
     }
     const unsigned tile_step = (unsigned)(64 * rs * 2);
     auto issue = [&](int t, int stage) {
@@ -310,7 +320,7 @@ __global__ __launch_bounds__(AT) void attn_fwd_bf16_kernel(const bf16_t* __restr
 #pragma unroll
     for (int ks = 0; ks < C::KS; ++ks) koff[ks] = row_off<HD>(r, ks * 2 + h2);
     const int g = lane >> 4, i16 = lane & 15;
-    const bool ones_lane = HD == 16 && (g & 1);
+    const bool ones_lane = HD == 16 && !SPL && (g & 1);
     int voff[2][C::DB];       // [row | row+8][d block]
 #pragma unroll
     for (int u = 0; u < 2; ++u)
@@ -345,14 +355,27 @@ __global__ __launch_bounds__(AT) void attn_fwd_bf16_kernel(const bf16_t* __restr
 #pragma unroll
             for (int ks = 0; ks < C::KS; ++ks) {
                 const short8_t kf = *reinterpret_cast<const short8_t*>(st + koff[ks] + kb * 32 * C::RB);
+                if constexpr (SPL) {
+                    const short8_t kfl = *reinterpret_cast<const short8_t*>(st + LO + koff[ks] + kb * 32 * C::RB);
+#pragma unroll
+                    for (int qi = 0; qi < QB; ++qi) {
+                        s[qi][kb] = mfma32(kfl, qf[qi][ks], s[qi][kb]);
+                        s[qi][kb] = mfma32(kf, qfl[qi][ks], s[qi][kb]);
+                    }
+                }
 #pragma unroll
                 for (int qi = 0; qi < QB; ++qi) s[qi][kb] = mfma32(kf, qf[qi][ks], s[qi][kb]);
             }
         }
         // V^T fragments for the whole tile: issued now, waited on just before the PV products
         short4_t vlo[C::DB][4], vhi[C::DB][4];
+        short4_t wlo[SPL ? C::DB : 1][4], whi[SPL ? C::DB : 1][4];      // SPL: the same fragments of the lo image of V
 #pragma unroll
         for (int db = 0; db < C::DB; ++db) tr_issue<C::RB>(sbase + voff[0][db], sbase + voff[1][db], vlo[db], vhi[db]);
+        if constexpr (SPL) {
+#pragma unroll
+            for (int db = 0; db < C::DB; ++db) tr_issue<C::RB>(sbase + LO + voff[0][db], sbase + LO + voff[1][db], wlo[db], whi[db]);
+        }
         if ((it + 1) * 64 > L) {   // ragged last tile only (uniform branch)
 #pragma unroll
             for (int qi = 0; qi < QB; ++qi)
@@ -387,7 +410,7 @@ __global__ __launch_bounds__(AT) void attn_fwd_bf16_kernel(const bf16_t* __restr
                 for (int db = 0; db < C::DB; ++db)
 #pragma unroll
                     for (int e = 0; e < 16; ++e) o[qi][db][e] *= alpha;
-                if constexpr (HD >= 32) {
+                if constexpr (HD >= 32 || SPL) {
 #pragma unroll
                     for (int u = 0; u < 4; ++u) lsum[qi][u] *= alpha;
                 }
@@ -398,34 +421,73 @@ __global__ __launch_bounds__(AT) void attn_fwd_bf16_kernel(const bf16_t* __restr
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
                     s[qi][kb][e] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[qi][kb][e], c, -mc));
-                    if constexpr (HD >= 32) lsum[qi][e & 3] += s[qi][kb][e];
+                    if constexpr (HD >= 32 || SPL) lsum[qi][e & 3] += s[qi][kb][e];
                 }
         }
         tr_wait(vlo[0], vhi[0]);
         if constexpr (C::DB == 2) tr_wait(vlo[1], vhi[1]);
+        if constexpr (SPL) {
+            tr_wait(wlo[0], whi[0]);
+            if constexpr (C::DB == 2) tr_wait(wlo[1], whi[1]);
+        }
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2)
+            for (int s2 = 0; s2 < 2; ++s2) {
+                bf16x8_t ph[QB], pl[SPL ? QB : 1];
+#pragma unroll
+                for (int qi = 0; qi < QB; ++qi) {
+                    ph[qi] = cvt8(s[qi][kb], s2);
+                    if constexpr (SPL) {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) pl[qi][j] = (__bf16)(s[qi][kb][8 * s2 + j] - (float)ph[qi][j]);
+                    }
+                }
 #pragma unroll
                 for (int db = 0; db < C::DB; ++db) {
                     const short8_t vf = join8(vlo[db][kb * 2 + s2], vhi[db][kb * 2 + s2]);
+                    if constexpr (SPL) {
+                        const short8_t vfl = join8(wlo[db][kb * 2 + s2], whi[db][kb * 2 + s2]);
 #pragma unroll
-                    for (int qi = 0; qi < QB; ++qi) o[qi][db] = mfma32(vf, cvt8(s[qi][kb], s2), o[qi][db]);
+                        for (int qi = 0; qi < QB; ++qi) {
+                            o[qi][db] = mfma32(vfl, ph[qi], o[qi][db]);
+                            o[qi][db] = mfma32(vf, pl[qi], o[qi][db]);
+                        }
+                    }
+#pragma unroll
+                    for (int qi = 0; qi < QB; ++qi) o[qi][db] = mfma32(vf, ph[qi], o[qi][db]);
                 }
+            }
     }
     __syncthreads();   // every wave is done with the ring before it becomes the store staging area
 #pragma unroll
     for (int qi = 0; qi < QB; ++qi) {
         const int qq = q0 + qi * 32;
         float l = o[qi][0][8];   // hd 16: the ones rows of V^T hold the row sums (both lane halves already combined by the MFMA)
-        if constexpr (HD >= 32) {
+        if constexpr (HD >= 32 || SPL) {
             l = (lsum[qi][0] + lsum[qi][1]) + (lsum[qi][2] + lsum[qi][3]);
             l += __shfl_xor(l, 32, 64);
         }
         if (h2 == 0 && qq + r < L) lse[((int64_t)nb * H + h) * L + qq + r] = m[qi] * c + log2f(l);
         if (qi > 0) __syncthreads();   // the staging rows of the previous block have been read
-        store_T<HD>(o[qi], 1.0f / l, smem + wave * 32 * C::RB, out + ((int64_t)nb * L + qq) * H * HD + h * HD, (int64_t)H * HD, L - qq, lane);
+        if constexpr (SPL) {
+            const float inv = 1.0f / l;
+            f32x16_t ol[C::DB];
+#pragma unroll
+            for (int db = 0; db < C::DB; ++db)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const float v = o[qi][db][e] * inv;
+                    o[qi][db][e] = v;
+                    ol[db][e] = v - bf2f(f2bf(v));
+                }
+            bf16_t* orow = out + ((int64_t)nb * L + qq) * 2 * H * HD + h * HD;
+            store_T<HD>(o[qi], 1.0f, smem + wave * 32 * C::RB, orow, (int64_t)2 * H * HD, L - qq, lane);
+            __syncthreads();
+            store_T<HD>(ol, 1.0f, smem + wave * 32 * C::RB, orow + H * HD, (int64_t)2 * H * HD, L - qq, lane);
+        } else {
+            store_T<HD>(o[qi], 1.0f / l, smem + wave * 32 * C::RB, out + ((int64_t)nb * L + qq) * H * HD + h * HD, (int64_t)H * HD, L - qq, lane);
+        }
     }
 }
 
@@ -1268,6 +1330,13 @@ static int fwd_bf16(const void* qkv, void* out, float* lse, int NB, int L, int H
     return 0;
 }
 template <int HD>
+static int fwd_split(const void* qkv, void* out, float* lse, int NB, int L, int H, float c, hipStream_t s) {
+    const size_t lds = 3 * 2 * (2 * ACfg<HD>::TILE + (HD == 16 ? 2048 : 0));
+    if (int rc = set_lds(attn_fwd_bf16_kernel<HD, 1, true>, lds)) return rc;
+    hipLaunchKernelGGL((attn_fwd_bf16_kernel<HD, 1, true>), dim3(cdiv(L, 128) * H * NB), dim3(AT), lds, s, (const bf16_t*)qkv, (bf16_t*)out, lse, L, H, c);
+    return 0;
+}
+template <int HD>
 static int bwd_bf16(const void* qkv, const void* out, const void* dout, const float* lse, const float* ws, void* dqkv, int NB, int L, int H,
                     float c, float scale, hipStream_t s) {
     const float* delta = ws;                           // negated
@@ -1309,7 +1378,7 @@ static void bwd_f32(const void* qkv, const void* dout, const float* lse, const f
 static int attn_check(const char* who, int NB, int L, int H, int hd, int dt) {
     STAR_CHECK(NB > 0 && L > 0 && H > 0, "%s: bad shape NB=%d L=%d H=%d", who, NB, L, H);
     STAR_CHECK(hd == 16 || hd == 32 || hd == 64, "%s: head dim %d not in {16,32,64}", who, hd);
-    STAR_CHECK(dt == STAR_BF16 || dt == STAR_F32, "%s: unknown dtype %d", who, dt);
+    STAR_CHECK(dt == STAR_BF16 || dt == STAR_F32 || dt == STAR_BF16X3, "%s: unknown dtype %d", who, dt);
     STAR_CHECK(H <= 65535 && NB <= 65535 && (int64_t)cdiv(L, 128) * H * NB < (1ll << 31), "%s: H, NB, L too large for the grid", who);
     return 0;
 }
@@ -1320,7 +1389,12 @@ extern "C" int star_attn_fwd(const void* qkv, void* out, float* lse, int NB, int
     hipStream_t s = (hipStream_t)stream;
     const float c = (float)((double)LOG2E / sqrt((double)hd));
     int rc = 0;
-    if (dt == STAR_BF16) {
+    if (dt == STAR_BF16X3) {
+        STAR_CHECK((long long)L * 6 * H * hd * 2 < 0x7fffffffLL, "star_attn_fwd(bf16x3): sequence over 2 GiB");
+        if (hd == 16) rc = fwd_split<16>(qkv, out, lse, NB, L, H, c, s);
+        else if (hd == 32) rc = fwd_split<32>(qkv, out, lse, NB, L, H, c, s);
+        else rc = fwd_split<64>(qkv, out, lse, NB, L, H, c, s);
+    } else if (dt == STAR_BF16) {
         if (hd == 16) rc = fwd_bf16<16>(qkv, out, lse, NB, L, H, c, s);
         else if (hd == 32) rc = fwd_bf16<32>(qkv, out, lse, NB, L, H, c, s);
         else rc = fwd_bf16<64>(qkv, out, lse, NB, L, H, c, s);
@@ -1358,6 +1432,7 @@ extern "C" int star_attn_bwd_ws(const void* qkv, const void* out, const void* do
                                 int NB, int L, int H, int hd, int dt, void* stream) {
     STAR_CHECK(ws != nullptr, "star_attn_bwd_ws: null workspace");
     if (int rc = attn_check("star_attn_bwd_ws", NB, L, H, hd, dt)) return rc;
+    STAR_CHECK(dt != STAR_BF16X3, "star_attn_bwd_ws: STAR_BF16X3 is a forward-only storage type");
     STAR_CHECK(ws_bytes >= attn_bwd_ws_floats(NB, L, H, hd, dt) * 4, "star_attn_bwd_ws: workspace of %lld bytes, %lld needed (star_attn_bwd_ws_bytes)",
                (long long)ws_bytes, (long long)(attn_bwd_ws_floats(NB, L, H, hd, dt) * 4));
     return attn_bwd_impl(qkv, out, dout, lse, ws, ws + 2 * (int64_t)NB * H * L, dqkv, NB, L, H, hd, dt, stream);
@@ -1368,6 +1443,7 @@ static int attn_bwd_impl(const void* qkv, const void* out, const void* dout, con
                          int NB, int L, int H, int hd, int dt, void* stream) {
     STAR_CHECK(qkv && out && dout && lse && delta && dqkv, "star_attn_bwd: null pointer");
     if (int rc = attn_check("star_attn_bwd", NB, L, H, hd, dt)) return rc;
+    STAR_CHECK(dt != STAR_BF16X3, "star_attn_bwd: STAR_BF16X3 is a forward-only storage type");
     hipStream_t s = (hipStream_t)stream;
     const float scale = (float)(1.0 / sqrt((double)hd));
     const float c = (float)((double)LOG2E / sqrt((double)hd));

@@ -276,12 +276,15 @@ __device__ __forceinline__ int ntf_swz(int row) { return (0x78 >> (((row >> 2) &
 template <int CG> __device__ __forceinline__ int ntf_run_off(int lg, int a) {
     return CG == 8 ? ((a >> 1) * 32 + lg * 8 + (a & 1) * 4) : (a * 16 + lg * 4);
 }
-template <int NST, int EPI, int WM, int WN, int RB, int CG>
-__global__ __launch_bounds__(WM * WN * 64) __attribute__((amdgpu_waves_per_eu(WM * WN == 4 ? 3 : (RB == 8 ? 2 : 4))))
+// SPL = 1 (dt = STAR_BF16X3): operands are bf16 PAIRS hi + lo (a row of A / W is [hi (K) | lo (K)], an out_lp row [hi (N) | lo (N)])
+// and every k-step runs three MFMA products hi*hi + lo*hi + hi*lo on the bf16 pipe -- float32-grade products (2^-17 per operand,
+// the lo*lo term of 2^-18 dropped) at 3 MFMAs for 2x the operand bytes.  A stage then holds the hi images followed by the lo images.
+template <int NST, int EPI, int WM, int WN, int RB, int CG, int SPL = 0>
+__global__ __launch_bounds__(WM * WN * 64) __attribute__((amdgpu_waves_per_eu(SPL ? 2 : (WM * WN == 4 ? 3 : (RB == 8 ? 2 : 4)))))
 void gemm_nt_fast_kernel(const StarGemm g) {
     static_assert(CG == 4 || CG == 8, "column groups of 4 (float32 outputs) or 8 (bf16 outputs)");
-    constexpr int NW = WM * WN, BM = WM * RB * 16, BN = WN * 64, STAGE = (BM + BN) * 64, PF = NST - 1;
-    constexpr int NA = BM / 16 / NW, NWP = BN / 16 / NW, NDMA = NA + NWP;   // LDS-DMA pieces (16 rows x 64 B) per wave and stage
+    constexpr int NW = WM * WN, BM = WM * RB * 16, BN = WN * 64, HALF = (BM + BN) * 64, STAGE = HALF * (SPL ? 2 : 1), PF = NST - 1;
+    constexpr int NA = BM / 16 / NW, NWP = BN / 16 / NW, NDMA = (NA + NWP) * (SPL ? 2 : 1);   // LDS-DMA pieces (16 rows x 64 B) per wave and stage
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int M = g.M, N = g.N, K = g.K;
     const int tiles_n = (N + BN - 1) / BN, tiles_m = (M + BM - 1) / BM, ntiles = tiles_m * tiles_n;
@@ -294,7 +297,11 @@ void gemm_nt_fast_kernel(const StarGemm g) {
     __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g.A), 0, 0x7fffffff, 0x00020000);
     __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g.W), 0, 0x7fffffff, 0x00020000);
     unsigned offA[2], offW[2];   // NA, NWP <= 2 (fixed bounds: a dependent bound here makes hipcc drop the kernel on the host side)
+    unsigned offAl[2], offWl[2]; // SPL: the lo halves (K elements further along the row; out of range for a plain-bf16 A operand)
+    int colA[2], colW[2];        // SPL: element column of the lane's 16-byte chunk inside a k-step (K % 32 != 0: the last step is cut)
     static_assert(NA <= 2 && NWP <= 2, "LDS-DMA offset tables hold two pieces");
+    const bool a_plain = SPL && (g.flags & STAR_GEMM_A_PLAIN) != 0;
+    const long long lda = SPL && !a_plain ? 2LL * K : K, ldw = SPL ? 2LL * K : K;      // row pitch in elements
     auto dma_setup = [&](int m_blk, int n_blk) {
 #pragma unroll
         for (int j = 0; j < NA; ++j) {
@@ -303,7 +310,9 @@ void gemm_nt_fast_kernel(const StarGemm g) {
             const int m = m_blk + r;
             long long src = -1;
             if (m < M) src = g.a_rows ? (long long)g.a_rows[m] : (long long)m;
-            offA[j] = src >= 0 ? (unsigned)(src * K * 2 + c * 16) : 0x7fffffffu;
+            offA[j] = src >= 0 ? (unsigned)(src * lda * 2 + c * 16) : 0x7fffffffu;
+            offAl[j] = (src >= 0 && !a_plain) ? offA[j] + (unsigned)(K * 2) : 0x7fffffffu;
+            colA[j] = c * 8;
         }
 #pragma unroll
         for (int j = 0; j < NWP; ++j) {
@@ -312,7 +321,9 @@ void gemm_nt_fast_kernel(const StarGemm g) {
             // LDS row r = a*16 + lg*4 + j (within its 64-row block) holds W row = the output column of accumulator
             // (a, lg, j): see ntf_run_off
             const int n = n_blk + (r & ~63) + ntf_run_off<CG>((r >> 2) & 3, (r >> 4) & 3) + (r & 3);
-            offW[j] = n < N ? (unsigned)((long long)n * K * 2 + c * 16) : 0x7fffffffu;
+            offW[j] = n < N ? (unsigned)((long long)n * ldw * 2 + c * 16) : 0x7fffffffu;
+            offWl[j] = n < N ? offW[j] + (unsigned)(K * 2) : 0x7fffffffu;
+            colW[j] = c * 8;
         }
     };
     auto issue = [&](int kt) {
@@ -326,6 +337,42 @@ void gemm_nt_fast_kernel(const StarGemm g) {
         for (int j = 0; j < NWP; ++j)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (__attribute__((address_space(3))) void*)(st + BM * 64 + (wave * NWP + j) * 16 * 64), 16,
                                                      offW[j] + kb, 0, 0, 0);
+        if constexpr (SPL != 0) {
+#pragma unroll
+            for (int j = 0; j < NA; ++j)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (__attribute__((address_space(3))) void*)(st + HALF + (wave * NA + j) * 16 * 64), 16,
+                                                         offAl[j] + kb, 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < NWP; ++j)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (__attribute__((address_space(3))) void*)(st + HALF + BM * 64 + (wave * NWP + j) * 16 * 64), 16,
+                                                         offWl[j] + kb, 0, 0, 0);
+        }
+    };
+    // SPL with K % 32 != 0 (K % 8 == 0): the last k-step's chunks past column K read as zeros (an out-of-range offset) instead of
+    // running into the neighbouring half of the row
+    auto issue_tail = [&](int kt) {
+        unsigned char* st = smem + (kt % NST) * STAGE;
+        const unsigned kb = kt * (NTF_BK * 2);
+        const int k0 = kt * NTF_BK;
+#pragma unroll
+        for (int j = 0; j < NA; ++j)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (__attribute__((address_space(3))) void*)(st + (wave * NA + j) * 16 * 64), 16,
+                                                     k0 + colA[j] < K ? offA[j] + kb : 0x7fffffffu, 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < NWP; ++j)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (__attribute__((address_space(3))) void*)(st + BM * 64 + (wave * NWP + j) * 16 * 64), 16,
+                                                     k0 + colW[j] < K ? offW[j] + kb : 0x7fffffffu, 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < NA; ++j)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (__attribute__((address_space(3))) void*)(st + HALF + (wave * NA + j) * 16 * 64), 16,
+                                                     k0 + colA[j] < K ? offAl[j] + kb : 0x7fffffffu, 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < NWP; ++j)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (__attribute__((address_space(3))) void*)(st + HALF + BM * 64 + (wave * NWP + j) * 16 * 64), 16,
+                                                     k0 + colW[j] < K ? offWl[j] + kb : 0x7fffffffu, 0, 0, 0);
+    };
+    auto issue_any = [&](int kt, int nk_) {
+        if (SPL != 0 && kt == nk_ - 1 && (K % NTF_BK) != 0) issue_tail(kt); else issue(kt);
     };
     // fragment addresses inside a stage (constant over k-steps and tiles)
     int fw[4], fx[RB];
@@ -352,7 +399,7 @@ void gemm_nt_fast_kernel(const StarGemm g) {
     const bool has_res2 = GEN && g.res2 != nullptr;
     const int act = GEN ? g.act : (EPI == EPI_GELU_GRAD ? STAR_ACT_GELU : (EPI == EPI_MULAUX ? STAR_ACT_MULAUX : STAR_ACT_NONE));
     const bool use_aux = act == STAR_ACT_DGELU || act == STAR_ACT_MULAUX || act == STAR_ACT_DRELU;
-    const int nk = K / NTF_BK;
+    const int nk = SPL ? (K + NTF_BK - 1) / NTF_BK : K / NTF_BK;
 
     // ---- persistent over tiles (grid = resident blocks): the ring of the NEXT tile is filled while this tile's
     // epilogue runs, and the epilogue's stores drain under the next main loop.  Tiles t, t + grid, ... of one block
@@ -365,7 +412,7 @@ void gemm_nt_fast_kernel(const StarGemm g) {
         n_blk = (tile % tiles_n) * BN;
     }
     dma_setup(m_blk, n_blk);
-    for (int s0 = 0; s0 < PF && s0 < nk; ++s0) issue(s0);
+    for (int s0 = 0; s0 < PF && s0 < nk; ++s0) issue_any(s0, nk);
     bool first = true;
     while (true) {
         // ---- epilogue set-up, done BEFORE the main loop so that its global reads (row indices, the first two row
@@ -437,7 +484,28 @@ void gemm_nt_fast_kernel(const StarGemm g) {
                 if (rok[a]) *reinterpret_cast<float4*>(row + roff[a]) = make_float4(v[4 * a], v[4 * a + 1], v[4 * a + 2], v[4 * a + 3]);
         };
         auto st_runs_lp = [&](bf16_t* row, const float (&v)[16]) {
-            if constexpr (CG == 8) {
+            if constexpr (SPL != 0) {       // hi at column n, lo = bf16(v - hi) at column N + n
+                float lo[16];
+#pragma unroll
+                for (int e = 0; e < 16; ++e) lo[e] = v[e] - bf2f(f2bf(v[e]));
+                if constexpr (CG == 8) {
+#pragma unroll
+                    for (int h = 0; h < 2; ++h)
+                        if (rok[2 * h]) {
+                            *reinterpret_cast<uint4*>(row + roff[2 * h]) = make_uint4(pack_bf16(v[8 * h], v[8 * h + 1]), pack_bf16(v[8 * h + 2], v[8 * h + 3]),
+                                                                                      pack_bf16(v[8 * h + 4], v[8 * h + 5]), pack_bf16(v[8 * h + 6], v[8 * h + 7]));
+                            *reinterpret_cast<uint4*>(row + N + roff[2 * h]) = make_uint4(pack_bf16(lo[8 * h], lo[8 * h + 1]), pack_bf16(lo[8 * h + 2], lo[8 * h + 3]),
+                                                                                          pack_bf16(lo[8 * h + 4], lo[8 * h + 5]), pack_bf16(lo[8 * h + 6], lo[8 * h + 7]));
+                        }
+                } else {
+#pragma unroll
+                    for (int a = 0; a < 4; ++a)
+                        if (rok[a]) {
+                            *reinterpret_cast<uint2*>(row + roff[a]) = make_uint2(pack_bf16(v[4 * a], v[4 * a + 1]), pack_bf16(v[4 * a + 2], v[4 * a + 3]));
+                            *reinterpret_cast<uint2*>(row + N + roff[a]) = make_uint2(pack_bf16(lo[4 * a], lo[4 * a + 1]), pack_bf16(lo[4 * a + 2], lo[4 * a + 3]));
+                        }
+                }
+            } else if constexpr (CG == 8) {
 #pragma unroll
                 for (int h = 0; h < 2; ++h)
                     if (rok[2 * h])
@@ -464,27 +532,37 @@ void gemm_nt_fast_kernel(const StarGemm g) {
             // stages allowed to stay in flight behind stage kt; a later tile's first step also retires the previous
             // epilogue's stores and this tile's prefetches, whose number is not known: plain vmcnt(0)
             const int rem = (kt == 0 && !first) ? 0 : min(nk - 1 - kt, PF - 1);
-            if constexpr (NDMA == 4) {
-                if (rem >= 3) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-                else if (rem == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-                else if (rem == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            } else {
-                static_assert(NDMA == 3, "vmcnt table covers 3 or 4 LDS-DMA pieces per wave and stage");
-                if (rem >= 3) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
-                else if (rem == 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-                else if (rem == 1) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            }
+            static_assert(3 * NDMA <= 63, "counted vmcnt");
+            if (rem >= 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * NDMA) : "memory");
+            else if (rem == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NDMA) : "memory");
+            else if (rem == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
-            if (kt + PF < nk) issue(kt + PF);
+            if (kt + PF < nk) issue_any(kt + PF, nk);
             const unsigned char* st = smem + (kt % NST) * STAGE;
             short8_t w8[4], x8[RB];
 #pragma unroll
             for (int a = 0; a < 4; ++a) w8[a] = *reinterpret_cast<const short8_t*>(st + fw[a]);
 #pragma unroll
             for (int b = 0; b < RB; ++b) x8[b] = *reinterpret_cast<const short8_t*>(st + fx[b]);
+            if constexpr (SPL != 0) {
+                short8_t wl[4], xl[RB];
+#pragma unroll
+                for (int a = 0; a < 4; ++a) wl[a] = *reinterpret_cast<const short8_t*>(st + HALF + fw[a]);
+#pragma unroll
+                for (int b = 0; b < RB; ++b) xl[b] = *reinterpret_cast<const short8_t*>(st + HALF + fx[b]);
+                // the two small products first, the hi * hi product last (the order float32 would round least in)
+#pragma unroll
+                for (int a = 0; a < 4; ++a)
+#pragma unroll
+                    for (int b = 0; b < RB; ++b) {
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wl[a]), __builtin_bit_cast(bf16x8_t, x8[b]),
+                                                                            acc[a][b], 0, 0, 0);
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, w8[a]), __builtin_bit_cast(bf16x8_t, xl[b]),
+                                                                            acc[a][b], 0, 0, 0);
+                    }
+            }
 #pragma unroll
             for (int a = 0; a < 4; ++a)
 #pragma unroll
@@ -503,7 +581,7 @@ void gemm_nt_fast_kernel(const StarGemm g) {
             m_blk = (tile / tiles_n) * BM;
             n_blk = (tile % tiles_n) * BN;
             dma_setup(m_blk, n_blk);
-            for (int s0 = 0; s0 < PF && s0 < nk; ++s0) issue(s0);
+            for (int s0 = 0; s0 < PF && s0 < nk; ++s0) issue_any(s0, nk);
         }
 
         // ---- epilogue straight from the accumulators (its stores drain under the next tile's main loop)
@@ -553,7 +631,7 @@ void gemm_nt_fast_kernel(const StarGemm g) {
             if (by_arow && arow[b] < 0) {
 #pragma unroll
                 for (int e = 0; e < 16; ++e) v[e] = 0.f;
-                if (out_lp) st_runs_lp(out_lp + (size_t)d * N, v);
+                if (out_lp) st_runs_lp(out_lp + (size_t)d * (SPL ? 2 * N : N), v);
                 if (g.out_f32) st_runs(g.out_f32 + (size_t)d * N, v);
                 continue;
             }
@@ -610,7 +688,7 @@ void gemm_nt_fast_kernel(const StarGemm g) {
 #pragma unroll
                 for (int e = 0; e < 16; ++e) v[e] += t2[e];
             }
-            if (out_lp) st_runs_lp(out_lp + (size_t)d * N, v);
+            if (out_lp) st_runs_lp(out_lp + (size_t)d * (SPL ? 2 * N : N), v);
             if (g.out_f32) st_runs(g.out_f32 + (size_t)d * N, v);
         }
         }
@@ -860,6 +938,29 @@ static bool launch_nt_wreg(const StarGemm* g, hipStream_t s) {
     return true;
 }
 
+// dt = STAR_BF16X3: the 256 x 128 tile (8 waves, two per SIMD: 48 MFMAs per wave and k-step against 6 LDS-DMA pieces) for every
+// epilogue -- the per-wave accumulator block is the 128 x 128 tile's, so the epilogues keep their register budgets; a stage is
+// 48 KB (hi and lo images), the ring 144 KB: one workgroup per CU.
+template <int EPI, int CG>
+static void launch_nt_split_cg(const StarGemm* g, hipStream_t s) {
+    constexpr int NST = 3, WM = 4, WN = 2, RB = 4, BM = WM * RB * 16, BN = WN * 64;
+    constexpr int LDS = NST * 2 * (BM + BN) * 64;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_fast_kernel<NST, EPI, WM, WN, RB, CG, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    hipLaunchKernelGGL((gemm_nt_fast_kernel<NST, EPI, WM, WN, RB, CG, 1>), dim3(cdiv(g->M, BM) * cdiv(g->N, BN)), dim3(WM * WN * 64), LDS, s, *g);
+}
+template <int EPI>
+static void launch_nt_split_epi(const StarGemm* g, hipStream_t s) {
+    if (g->out_lp) launch_nt_split_cg<EPI, 8>(g, s); else launch_nt_split_cg<EPI, 4>(g, s);
+}
+static int launch_nt_split(const StarGemm* g, hipStream_t s) {
+    const bool plain = !g->res2 && g->act == STAR_ACT_NONE;
+    if (plain && !g->res) launch_nt_split_epi<EPI_LINEAR>(g, s);
+    else if (plain) launch_nt_split_epi<EPI_RES>(g, s);
+    else if (g->act == STAR_ACT_GELU && !g->res && !g->res2) launch_nt_split_epi<EPI_GELU_GRAD>(g, s);
+    else launch_nt_split_epi<EPI_GENERIC>(g, s);
+    return 0;
+}
+
 template <int NST>
 static int launch_nt_fast(const StarGemm* g, hipStream_t s) {
     const bool plain = !g->res2 && !g->aux && !g->pre && g->act == STAR_ACT_NONE;
@@ -886,7 +987,20 @@ static int launch_nt(const StarGemm* g, hipStream_t s) {
 extern "C" int star_gemm(const StarGemm* g, void* stream) {
     STAR_CHECK(g && g->A && g->W, "star_gemm: null operand");
     STAR_CHECK(g->M >= 0 && g->N > 0 && g->K > 0, "star_gemm: bad shape M=%d N=%d K=%d", g->M, g->N, g->K);
-    STAR_CHECK(g->dt == STAR_BF16 || g->dt == STAR_F32, "star_gemm: unknown dtype %d", g->dt);
+    STAR_CHECK(g->dt == STAR_BF16 || g->dt == STAR_F32 || g->dt == STAR_BF16X3, "star_gemm: unknown dtype %d", g->dt);
+    if (g->dt == STAR_BF16X3) {
+        STAR_CHECK(g->K % 8 == 0 && g->N % 16 == 0, "star_gemm(bf16x3): K=%d must be a multiple of 8 and N=%d of 16", g->K, g->N);
+        STAR_CHECK(!g->pre && !g->aux && (g->act == STAR_ACT_NONE || g->act == STAR_ACT_GELU || g->act == STAR_ACT_RELU),
+                   "star_gemm(bf16x3): forward epilogues only (no pre-activation output, no activation gradients)");
+        STAR_CHECK(g->out_lp || g->out_f32, "star_gemm: no output");
+        STAR_CHECK(!g->res2 || (g->res2_div > 0 && g->res2_mod > 0), "star_gemm: res2 needs div/mod");
+        STAR_CHECK(((reinterpret_cast<uintptr_t>(g->A) | reinterpret_cast<uintptr_t>(g->W)) & 15) == 0, "star_gemm(bf16x3): operands must be 16-byte aligned");
+        STAR_CHECK((long long)g->N * g->K * 4 < 0x7fffffffLL, "star_gemm(bf16x3): weight over 2 GiB");
+        if (g->M == 0) return 0;
+        launch_nt_split(g, (hipStream_t)stream);
+        STAR_LAUNCH_CHECK("star_gemm(bf16x3)");
+        return 0;
+    }
     const int epc = g->dt == STAR_BF16 ? 8 : 4;
     STAR_CHECK(g->K % epc == 0, "star_gemm: K=%d must be a multiple of %d", g->K, epc);
     STAR_CHECK(g->N % 4 == 0, "star_gemm: N=%d must be a multiple of 4", g->N);

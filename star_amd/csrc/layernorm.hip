@@ -10,7 +10,8 @@
 #define LN_BWD_BLOCKS 768   // partial dgamma/dbeta rows = workgroups: three per CU (A/B inside the step: 768 beats 512, 1024 and 2048 by 0.3-0.5 %; final round-2 build: 768 11.89-11.91 ms, 1024 11.89-11.92, 512 12.02-12.06)
 #define LN_BWD_THREADS 512  // 8 waves: 1024 blocks put 8 waves on every SIMD, each with one row's loads in flight
 
-template <typename T, int NV>
+// SPLIT (dt = STAR_BF16X3): y rows are [hi (D) | lo (D)] bf16 pairs, hi = bf16(o), lo = bf16(o - hi)
+template <typename T, int NV, bool SPLIT = false>
 __global__ __launch_bounds__(LN_THREADS) void ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, T* __restrict__ y,
                                                             float* __restrict__ mean, float* __restrict__ rstd, int M,
@@ -48,7 +49,7 @@ __global__ __launch_bounds__(LN_THREADS) void ln_fwd_kernel(const float* __restr
         if (mean) mean[row] = mu;
         if (rstd) rstd[row] = rs;
     }
-    T* yr = y + (size_t)row * D;
+    T* yr = y + (size_t)row * (SPLIT ? 2 * D : D);
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         const int c = lane + i * 64;
@@ -59,6 +60,12 @@ __global__ __launch_bounds__(LN_THREADS) void ln_fwd_kernel(const float* __restr
 #pragma unroll
             for (int k = 0; k < 4; ++k) o[k] = (v[i][k] - mu) * rs * g[k] + b[k];
             st4(yr + c * 4, o);
+            if constexpr (SPLIT) {
+                float lo[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) lo[k] = o[k] - bf2f(f2bf(o[k]));
+                st4(yr + D + c * 4, lo);
+            }
         }
     }
 }
@@ -189,7 +196,10 @@ extern "C" int star_layernorm_fwd(const float* x, const float* gamma, const floa
     dim3 grid(cdiv(M, LN_THREADS / 64));
 #define LN_FWD(NV)                                                                                                  \
     do {                                                                                                            \
-        if (dt == STAR_BF16)                                                                                        \
+        if (dt == STAR_BF16X3)                                                                                      \
+            hipLaunchKernelGGL((ln_fwd_kernel<bf16_t, NV, true>), grid, dim3(LN_THREADS), 0, (hipStream_t)stream, x, gamma, \
+                               beta, (bf16_t*)y, mean, rstd, M, D, eps);                                            \
+        else if (dt == STAR_BF16)                                                                                   \
             hipLaunchKernelGGL((ln_fwd_kernel<bf16_t, NV>), grid, dim3(LN_THREADS), 0, (hipStream_t)stream, x, gamma, \
                                beta, (bf16_t*)y, mean, rstd, M, D, eps);                                            \
         else                                                                                                        \

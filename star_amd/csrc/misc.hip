@@ -82,7 +82,11 @@ __device__ __forceinline__ void cast_tile(const StarCastJob& job, D* __restrict_
             const int r = r0 + i, c = c0 + tx;
             if (r < job.rows && c < job.cols) {
                 const int sr = job.src_rows ? job.src_rows[r] : r;
-                Act<D>::st(dst + (size_t)r * ld + c, job.src[(size_t)sr * job.cols + c]);
+                const float v = job.src[(size_t)sr * job.cols + c];
+                Act<D>::st(dst + (size_t)r * ld + c, v);
+                if constexpr (sizeof(D) == 2) {      // bf16 pair: the remainder goes `cols` elements further along the row
+                    if (job.split) Act<D>::st(dst + (size_t)r * ld + job.cols + c, v - bf2f(f2bf(v)));
+                }
             }
         }
         return;

@@ -15,7 +15,7 @@ import os
 import torch
 
 from . import ops
-from ._lib import ACT_DRELU, ACT_GELU, ACT_MULAUX, ACT_NONE, ACT_RELU, BF16, F32, GEMM_PRE_IS_GRAD, GEMM_RES_BY_AROW
+from ._lib import ACT_DRELU, ACT_GELU, ACT_MULAUX, ACT_NONE, ACT_RELU, BF16, BF16X3, F32, GEMM_A_PLAIN, GEMM_PRE_IS_GRAD, GEMM_RES_BY_AROW
 
 _LINEARS_BLOCK = ("attn.qkv", "attn.proj", "mlp.fc1", "mlp.fc2")
 SIDE_STREAM = os.environ.get("STAR_AMD_SIDE_STREAM", "1") != "0"   # weight gradients on a second stream
@@ -109,6 +109,10 @@ class Weights:
         """The dt copy of weight `w` ([N,K], or [K,N] when transposed)."""
         def make():
             n, k = w.shape
+            if dt == BF16X3:       # rows of [hi | lo] (forward only: no transposed copies)
+                assert not transposed
+                dst = torch.empty(n, 2 * k, dtype=torch.bfloat16, device=w.device)
+                return dst, [(w.detach(), dst, False, dict(dst_ld=2 * k, split=True))]
             dst = torch.empty((k, n) if transposed else (n, k), dtype=ops.L.torch_dtype(dt), device=w.device)
             return dst, [(w.detach(), dst, transposed)]
         return self.jobs_entry(key, (w,), dt, make)
@@ -137,6 +141,11 @@ def _heads(P, W, cfg, dt, transposed=False):
     def make():
         idx = head_permutation(cfg, wo.device)
         v, k = wf.shape
+        if dt == BF16X3:
+            assert not transposed
+            dst = torch.empty(2 * v, 2 * k, dtype=torch.bfloat16, device=wo.device)
+            return dst, [(wf.detach(), dst, False, dict(src_rows=idx, dst_ld=2 * k, dst_off=0, split=True)),
+                         (wo.detach(), dst, False, dict(src_rows=idx, dst_ld=2 * k, dst_off=v * 2 * k, split=True))]
         dst = torch.empty((k, 2 * v) if transposed else (2 * v, k), dtype=ops.L.torch_dtype(dt), device=wo.device)
         if transposed:
             return dst, [(wf.detach(), dst, True, dict(src_rows=idx, dst_ld=2 * v, dst_off=0)),
@@ -167,7 +176,8 @@ def _patch_weight(P, W, cfg, dt, channels_last):
     def build():
         w2 = w.detach()
         w2 = w2.permute(0, 2, 3, 1) if channels_last else w2     # (py, px, c) order for NHWC memory
-        return ops.cast(w2.reshape(w.shape[0], -1).contiguous(), dt)
+        w2 = w2.reshape(w.shape[0], -1).contiguous()
+        return ops.cast_split(w2) if dt == BF16X3 else ops.cast(w2, dt)
 
     return W.get(("patch", dt, channels_last), w._version, build)
 
@@ -179,31 +189,31 @@ def _block_fwd(x, P, W, pre, heads, nb, l, dt, eps, save, train, ln1=None, nxt=N
     ln = (h, mean, rstd) of that LayerNorm (from the fc2 kernel where star_gemm_res_ln covers the shape), else x_out alone."""
     d = x.shape[1]
     hd = d // heads
-    fuse_ln = _GEMM_LN and ops.gemm_res_ln_prefers(x.shape[0], d, d, dt)
+    fuse_ln = _GEMM_LN and dt == BF16 and ops.gemm_res_ln_prefers(x.shape[0], d, d, dt)
     h1, mean1, rstd1 = ln1 if ln1 is not None else ops.layernorm_fwd(x, P[pre + "norm1.weight"], P[pre + "norm1.bias"], eps, dt, want_stats=train)
-    qkv, _, _ = ops.gemm(h1, _lin(P, W, pre + "attn.qkv", dt), bias=P[pre + "attn.qkv.bias"])
-    a, lse = ops.attn_fwd(qkv, nb, l, heads, hd)
+    qkv, _, _ = ops.gemm(h1, _lin(P, W, pre + "attn.qkv", dt), bias=P[pre + "attn.qkv.bias"], dt=dt)
+    a, lse = ops.attn_fwd(qkv, nb, l, heads, hd, dt=dt)
     if fuse_ln:      # x_mid = x + proj(a) and norm2(x_mid) in one launch
         x_mid, h2, mean2, rstd2 = ops.gemm_res_ln(a, _lin(P, W, pre + "attn.proj", dt), P[pre + "attn.proj.bias"], x, P[pre + "norm2.weight"],
                                                   P[pre + "norm2.bias"], eps, want_stats=train, out=None if train else x)
     else:
         _, x_mid, _ = ops.gemm(a, _lin(P, W, pre + "attn.proj", dt), bias=P[pre + "attn.proj.bias"], res=x, want_lp=False,
-                               want_f32=True, out_f32=None if train else x)
+                               want_f32=True, out_f32=None if train else x, dt=dt)
         h2, mean2, rstd2 = ops.layernorm_fwd(x_mid, P[pre + "norm2.weight"], P[pre + "norm2.bias"], eps, dt, want_stats=train)
     # u is not the pre-activation but gelu'(pre-activation): all the backward needs of it (flag PRE_IS_GRAD)
     w1, w2 = _lin(P, W, pre + "mlp.fc1", dt), _lin(P, W, pre + "mlp.fc2", dt)
     ln = None
-    if _MLP_FUSED and ops.mlp_supported(d, w1.shape[0], dt):
+    if _MLP_FUSED and dt == BF16 and ops.mlp_supported(d, w1.shape[0], dt):
         x_out, v, u = ops.mlp_fwd(h2, w1, P[pre + "mlp.fc1.bias"], w2, P[pre + "mlp.fc2.bias"], x_mid, train, out=None if train else x_mid)
     else:
-        v, _, u = ops.gemm(h2, w1, bias=P[pre + "mlp.fc1.bias"], act=ACT_GELU, want_pre=train, flags=GEMM_PRE_IS_GRAD)
-        if nxt is not None and _GEMM_LN and ops.gemm_res_ln_prefers(x.shape[0], d, w1.shape[0], dt):
+        v, _, u = ops.gemm(h2, w1, bias=P[pre + "mlp.fc1.bias"], act=ACT_GELU, want_pre=train, flags=GEMM_PRE_IS_GRAD, dt=dt)
+        if nxt is not None and _GEMM_LN and dt == BF16 and ops.gemm_res_ln_prefers(x.shape[0], d, w1.shape[0], dt):
             x_out, hn, mean_n, rstd_n = ops.gemm_res_ln(v, w2, P[pre + "mlp.fc2.bias"], x_mid, P[nxt + ".weight"], P[nxt + ".bias"], eps,
                                                         want_stats=train, out=None if train else x_mid)
             ln = (hn, mean_n, rstd_n)
         else:
             _, x_out, _ = ops.gemm(v, w2, bias=P[pre + "mlp.fc2.bias"], res=x_mid, want_lp=False, want_f32=True,
-                                   out_f32=None if train else x_mid)
+                                   out_f32=None if train else x_mid, dt=dt)
     if train:
         save.append(dict(pre=pre, x=x, mean1=mean1, rstd1=rstd1, h1=h1, qkv=qkv, a=a, lse=lse, x_mid=x_mid, mean2=mean2,
                          rstd2=rstd2, h2=h2, u=u, v=v, heads=heads, nb=nb, l=l))
@@ -459,6 +469,9 @@ def forward(cfg, P, W, dt, imgs1, imgs_next, trans_matrices, num_agent, batch, m
             vq_update=False, theta=None):
     """Runs the model.  Returns (out, ctx): out = dict(loss [1], result, latent, ind); ctx feeds backward()."""
     dev = imgs1.device
+    if dt == BF16X3 and (train or cfg.vq):
+        raise RuntimeError("star_amd: compute dtype 'bf16x3' (bf16 hi/lo pairs) is an inference mode of the STAR completion model: "
+                           "train in 'bf16' or 'fp32', and run VQ-STAR in those")
     ba, c, hh, ww = imgs1.shape
     assert hh == ww == cfg.img and c == cfg.chans, (imgs1.shape, cfg.img, cfg.chans)
     T, L, D, Dd, p = cfg.T, cfg.L, cfg.dim, cfg.ddim, cfg.patch
@@ -483,15 +496,17 @@ def forward(cfg, P, W, dt, imgs1, imgs_next, trans_matrices, num_agent, batch, m
 
     # ---- encoder (K1, K2, K3, K4) -------------------------------------------------------------------------
     channels_last = imgs1.stride(1) == 1 and c > 1
-    a_pe = ops.patchify(imgs1, imgs_next if T > 1 else None, T, p, dt, channels_last_order=channels_last)
+    # BF16X3: the patches are 0/1 occupancy values, exact in plain bf16 -- only the weight is a hi/lo pair (GEMM_A_PLAIN)
+    a_pe = ops.patchify(imgs1, imgs_next if T > 1 else None, T, p, BF16 if dt == BF16X3 else dt, channels_last_order=channels_last)
+    pe_flags = GEMM_A_PLAIN if dt == BF16X3 else 0
     w_pe = _patch_weight(P, W, cfg, dt, channels_last)
     pos = P["pos_embed"][0, 1:]
     if cfg.encode_partial:
         _, x, _ = ops.gemm(a_pe, w_pe, bias=P["patch_embed.proj.bias"], res=pos, res_mod=L, a_rows=src_row, want_lp=False,
-                           want_f32=True, flags=GEMM_RES_BY_AROW)
+                           want_f32=True, flags=GEMM_RES_BY_AROW | pe_flags, dt=dt)
         l_enc = keep
     else:
-        _, x, _ = ops.gemm(a_pe, w_pe, bias=P["patch_embed.proj.bias"], res=pos, res_mod=L, want_lp=False, want_f32=True)
+        _, x, _ = ops.gemm(a_pe, w_pe, bias=P["patch_embed.proj.bias"], res=pos, res_mod=L, want_lp=False, want_f32=True, flags=pe_flags, dt=dt)
         l_enc = L
     if taps is not None:
         taps["x0"] = x.clone()
@@ -501,7 +516,7 @@ def forward(cfg, P, W, dt, imgs1, imgs_next, trans_matrices, num_agent, batch, m
         taps["enc_norm"] = y.clone()
     comp_rows = None if cfg.encode_partial else src_row
     latent_lp, latent, _ = ops.gemm(y, _lin(P, W, "compressor.0", dt), m=n_frames * keep, bias=P["compressor.0.bias"],
-                                    act=ACT_RELU, a_rows=comp_rows, want_f32=True)
+                                    act=ACT_RELU, a_rows=comp_rows, want_f32=True, dt=dt)
 
     # ---- vector quantiser between compressor and decompressor (VQ-STAR only; VQSTAR.py:432,456) -------------------
     vq = None
@@ -526,7 +541,7 @@ def forward(cfg, P, W, dt, imgs1, imgs_next, trans_matrices, num_agent, batch, m
                               cfg.vq_epsilon)
 
     # ---- decoder ----------------------------------------------------------------------------------------------
-    z, _, _ = ops.gemm(dec_in_lp, _lin(P, W, "decompressor", dt), bias=P["decompressor.bias"])
+    z, _, _ = ops.gemm(dec_in_lp, _lin(P, W, "decompressor", dt), bias=P["decompressor.bias"], dt=dt)
     dpos = P["decoder_pos_embed"][0, 1:]
     temp = None if cfg.no_temp_emb else P["decoder_temp_embed"].reshape(T, Dd)
     tok = P["mask_token"].reshape(Dd)
@@ -534,13 +549,13 @@ def forward(cfg, P, W, dt, imgs1, imgs_next, trans_matrices, num_agent, batch, m
     if not random_mode:
         xd = torch.empty(ba * L, Dd, dtype=torch.float32, device=dev)
         ops.gemm(z, w_de, bias=P["decoder_embed.bias"], c_rows=dst_row, out_rows=ba * L, res=dpos, res_mod=L, res2=temp,
-                 res2_div=keep, res2_mod=T, want_lp=False, want_f32=True, out_f32=xd)
+                 res2_div=keep, res2_mod=T, want_lp=False, want_f32=True, out_f32=xd, dt=dt)
         if cfg.decode_singletemp:      # rows no slice of timestamp 0 covers: mask token, no temporal embedding
             ops.fill_rows(xd, fill, tok, None, dpos, ba, L)
     else:
         val = torch.empty(ba * L, Dd, dtype=torch.float32, device=dev)
         ops.gemm(z, w_de, bias=P["decoder_embed.bias"], c_rows=dst_row, out_rows=ba * L, res2=temp, res2_div=keep, res2_mod=T,
-                 want_lp=False, want_f32=True, out_f32=val)
+                 want_lp=False, want_f32=True, out_f32=val, dt=dt)
         ops.fill_rows(val, fill, tok, None if temp is None else temp[0], None, ba, L)
         xd = ops.transpose_rows(val, dpos, ba, L, Dd)                      # Q2
         if taps is not None:
@@ -551,10 +566,10 @@ def forward(cfg, P, W, dt, imgs1, imgs_next, trans_matrices, num_agent, batch, m
                                          train, taps, "dec_blk%d")
     if taps is not None:
         taps["dec_norm"] = yd.clone()
-    _, logits, _ = ops.gemm(yd, _heads(P, W, cfg, dt), bias=_heads_bias(P, W, cfg, dt), want_lp=False, want_f32=True)
+    _, logits, _ = ops.gemm(yd, _heads(P, W, cfg, dt), bias=_heads_bias(P, W, cfg, dt), want_lp=False, want_f32=True, dt=dt)
 
     # ---- loss, decision, fusion (K9, K10) -----------------------------------------------------------------------
-    ce = ops.ce_argmax(logits, imgs1, p, dt, want_pred=taps is not None, want_dlogits=train)
+    ce = ops.ce_argmax(logits, imgs1, p, BF16 if dt == BF16X3 else dt, want_pred=taps is not None, want_dlogits=train)
     if taps is not None:
         taps["pred"], taps["mask"], taps["ids_restore"] = ce["pred"], mask, ids_restore
     if theta is None:    # a captured graph brings the pose table in a static device buffer instead (star_amd/graph.py)

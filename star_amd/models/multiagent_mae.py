@@ -14,7 +14,7 @@ import torch
 import torch.nn as nn
 
 from .. import engine
-from .._lib import BF16, F32
+from .._lib import BF16, BF16X3, F32
 from .mae_base import MultiAgentMaskedAutoencoderViT
 
 
@@ -88,13 +88,14 @@ class AmortizedIndivMMAEViT(MultiAgentMaskedAutoencoderViT):
 
     # ---- engine plumbing --------------------------------------------------------------------------------
     def set_compute_dtype(self, name):
-        """'bf16' (bf16 storage + MFMA, fp32 accumulation; default) or 'fp32' (the reference's numerics)."""
-        assert name in ("bf16", "fp32"), name
+        """'bf16' (bf16 storage + MFMA, fp32 accumulation; default), 'fp32' (the reference's numerics) or 'bf16x3' (inference only:
+        bf16 hi/lo pairs, three bf16 MFMA products per multiply -- float32-grade decisions at bf16-pipe speed)."""
+        assert name in ("bf16", "fp32", "bf16x3"), name
         self._compute_dtype = name
         return self
 
     def _dt(self):
-        return BF16 if self._compute_dtype == "bf16" else F32
+        return {"bf16": BF16, "fp32": F32, "bf16x3": BF16X3}[self._compute_dtype]
 
     def _cfg(self):
         if self._config is None:

@@ -9,7 +9,7 @@ import os
 import torch
 
 from . import _lib as L
-from ._lib import ACT_DGELU, ACT_DRELU, ACT_GELU, ACT_MULAUX, ACT_NONE, ACT_RELU, BF16, F32, p  # noqa: F401
+from ._lib import ACT_DGELU, ACT_DRELU, ACT_GELU, ACT_MULAUX, ACT_NONE, ACT_RELU, BF16, BF16X3, F32, GEMM_A_PLAIN, p  # noqa: F401
 
 
 class Profiler:
@@ -131,7 +131,7 @@ def layernorm_fwd(x, gamma, beta, eps, dt, want_stats=True):
     _cuda(x, gamma, beta)
     m, d = x.shape
     assert x.dtype == torch.float32 and x.is_contiguous()
-    y = torch.empty(m, d, dtype=L.torch_dtype(dt), device=x.device)
+    y = torch.empty(m, d * L.width(dt), dtype=L.torch_dtype(dt), device=x.device)       # BF16X3: rows of [hi | lo]
     mean = torch.empty(m, dtype=torch.float32, device=x.device) if want_stats else None
     rstd = torch.empty(m, dtype=torch.float32, device=x.device) if want_stats else None
     with _timed("layernorm_fwd", 0.0, float(m) * d * (4 + (2 if dt == BF16 else 4))):
@@ -178,27 +178,31 @@ def ln_fold_batch(tab, njobs, max_d):
 # ---------------------------------------------------------------------------------------------------
 def gemm(a, w, m=None, bias=None, act=ACT_NONE, res=None, res_mod=0, res2=None, res2_div=0, res2_mod=0, aux=None,
          a_rows=None, c_rows=None, out_rows=None, want_pre=False, want_lp=True, want_f32=False, out_f32=None, out_lp=None,
-         flags=0):
+         flags=0, dt=None):
     """C = epilogue(A[a_rows] @ W^T).  a [*, K], w [N, K] same dtype (bf16 or f32).
+    dt = BF16X3: w [N, 2K] and a [*, 2K] are bf16 hi/lo pairs (a [*, K] plain bf16 with flags & GEMM_A_PLAIN), out_lp [rows, 2N].
     Returns (out_lp, out_f32, pre) -- entries not requested are None."""
     _cuda(a, w)
-    dt = L.dt_of(a)
+    if dt is None:
+        dt = L.dt_of(a)
     assert w.dtype == a.dtype and a.is_contiguous() and w.is_contiguous()
-    k = a.shape[-1]
+    wd = L.width(dt)
+    k = w.shape[1] // wd
     n = w.shape[0]
-    assert w.shape[1] == k
+    assert a.shape[-1] == (k if (dt != BF16X3 or flags & GEMM_A_PLAIN) else 2 * k), (a.shape, w.shape, dt, flags)
     if m is None:
         m = a_rows.numel() if a_rows is not None else a.shape[0]
     rows_out = out_rows if out_rows is not None else m
     dev = a.device
     if want_lp and out_lp is None:
-        out_lp = (torch.zeros if c_rows is not None else torch.empty)(rows_out, n, dtype=a.dtype, device=dev)
+        out_lp = (torch.zeros if c_rows is not None else torch.empty)(rows_out, n * wd, dtype=a.dtype, device=dev)
     if want_f32 and out_f32 is None:
         out_f32 = (torch.zeros if c_rows is not None else torch.empty)(rows_out, n, dtype=torch.float32, device=dev)
+    assert not (want_pre and dt == BF16X3), "bf16x3 is a forward-only storage type"
     pre = torch.empty(rows_out, n, dtype=a.dtype, device=dev) if want_pre else None
     g = L.StarGemm(p(a), p(w), p(a_rows), p(c_rows), p(bias), p(res), res_mod, p(res2), res2_div, res2_mod, p(aux), act,
                    p(pre), p(out_lp), p(out_f32), m, n, k, dt, flags)
-    esz = a.element_size()
+    esz = a.element_size() * wd
     nbytes = (m * k + n * k) * esz + rows_out * n * ((esz if out_lp is not None else 0) + (4 if out_f32 is not None else 0) +
                                                       (esz if pre is not None else 0)) + m * n * ((4 if res is not None else 0) +
                                                                                                  (esz if aux is not None else 0))
@@ -333,12 +337,14 @@ def mlp_fwd(h, w1, b1, w2, b2, xres, train, out=None):
 
 
 # ---------------------------------------------------------------------------------------------------
-def attn_fwd(qkv, nb, l, h, hd):
-    """qkv [NB*L, 3*H*hd] -> (out [NB*L, H*hd], lse float32 [NB, H, L])."""
+def attn_fwd(qkv, nb, l, h, hd, dt=None):
+    """qkv [NB*L, 3*H*hd] -> (out [NB*L, H*hd], lse float32 [NB, H, L]).  dt = BF16X3: rows of bf16 hi/lo pairs, twice as wide."""
     _cuda(qkv)
-    dt = L.dt_of(qkv)
-    assert qkv.is_contiguous() and qkv.numel() == nb * l * 3 * h * hd
-    out = torch.empty(nb * l, h * hd, dtype=qkv.dtype, device=qkv.device)
+    if dt is None:
+        dt = L.dt_of(qkv)
+    wd = L.width(dt)
+    assert qkv.is_contiguous() and qkv.numel() == nb * l * 3 * h * hd * wd
+    out = torch.empty(nb * l, h * hd * wd, dtype=qkv.dtype, device=qkv.device)
     lse = torch.empty(nb, h, l, dtype=torch.float32, device=qkv.device)
     with _timed("attn_fwd", 4.0 * nb * h * l * l * hd):
         L.check(L.lib().star_attn_fwd(p(qkv), p(out), p(lse), nb, l, h, hd, dt, L.stream()))
@@ -480,17 +486,29 @@ def cast_batch_table(jobs, device):
         assert src.dtype == torch.float32 and src.is_contiguous() and dst.is_contiguous()
         assert idx is None or (idx.dtype == torch.int32 and idx.is_contiguous() and idx.device == dst.device)
         ld, off = int(ex.get("dst_ld", 0)), int(ex.get("dst_off", 0))
-        last = off + ((c - 1) * (ld or r) + r if tr else (r - 1) * (ld or c) + c)
+        last = off + ((c - 1) * (ld or r) + r if tr else (r - 1) * (ld or c) + c * (2 if ex.get("split") else 1))
         assert 0 <= off and last <= dst.numel(), "cast job writes past its destination"
         assert dst.dtype == (torch.float32 if ex.get("dst_f32") else dst.dtype) and (ex or dst.numel() == r * c)
+        split = bool(ex.get("split"))      # bf16 hi/lo pairs (BF16X3): the lo values sit `c` elements further along each row
+        assert not (split and (tr or ex.get("dst_f32"))) and (not split or ld >= 2 * c)
         rows.append([src.data_ptr(), dst.data_ptr(), r | (c << 32), int(bool(tr)) | (start << 32),      # StarCastJob, little endian
-                     idx.data_ptr() if idx is not None else 0, ld | (off << 32), int(bool(ex.get("dst_f32")))])
+                     idx.data_ptr() if idx is not None else 0, ld | (off << 32), int(bool(ex.get("dst_f32"))) | (int(split) << 32)])
         start += ((r + 63) // 64) * ((c + 63) // 64)
     return torch.tensor(rows, dtype=torch.int64).to(device), len(jobs), start
 
 
 def cast_batch(table, njobs, total_tiles, dt):
-    L.check(L.lib().star_cast_batch(p(table), njobs, total_tiles, dt, L.stream()))
+    L.check(L.lib().star_cast_batch(p(table), njobs, total_tiles, BF16 if dt == BF16X3 else dt, L.stream()))
+
+
+def cast_split(src):
+    """float32 [R, C] -> bf16 [R, 2C] hi/lo pairs (the BF16X3 storage of a weight)."""
+    assert src.dtype == torch.float32 and src.is_contiguous() and src.dim() == 2
+    r, c = src.shape
+    dst = torch.empty(r, 2 * c, dtype=torch.bfloat16, device=src.device)
+    tab, n, tiles = cast_batch_table([(src, dst, False, dict(dst_ld=2 * c, split=True))], src.device)
+    cast_batch(tab, n, tiles, BF16)
+    return dst
 
 
 def cast_back(src):
