@@ -7,8 +7,11 @@ path, then HIP against the (pinned) CPU oracle on the trained weights.
 
 What is asserted, with the values measured on MI355X (tools/measure_bf16_parity.py, profiles/r02_bf16_parity.log):
 
-  fp32 mode  identical decisions, fused maps and IoU on every trained fixture and at full size (0 flips of 2.56 M voxels);
+  fp32 mode  identical decisions, fused maps and IoU on every trained fixture; at full size identical except exact near-ties
+             (round 3 run: 1 flip of 2.56 M voxels, at a reference margin of 4e-6; the bound asserted is margin < 1e-3);
              logits within 3e-4 (|logit| up to 15), gradients within 1e-4 relative.
+  bf16x3     (inference; tests/test_bf16x3_gpu.py has the fixture assertions) the float32 mode's decisions: the same single
+             near-tie flips at full size, logits within 6e-4.
   bf16 mode  NOT identical: bf16 storage of MFMA operands perturbs the logits by ~0.25 % rms (max 2.8 % of the largest
              logit), which flips voxels whose two logits nearly tie.  Measured: 0 ... 1.6e-4 of the voxels on the trained
              fixtures (every flipped voxel has a reference margin < 0.021), 3.8e-5 at full size (margin < 0.071, median margin
@@ -114,35 +117,50 @@ def _grad_checks(mine, ref, ref_rw, ref_bound, rw_bound):
         assert e <= 0.06 * float(ref_rw[k].norm()) + 0.03 * gall_rw, (k, e, float(ref_rw[k].norm()), gall_rw)
 
 
-def _train_light(T, steps, B, A, nb):
+def _train_light(T, steps, B, A, nb, dtype="fp32", every=0):
+    """-> (state dict, last loss, [loss at steps every-1, 2 every-1, ...])"""
     from star_amd.models import multiagent_mae as mm
     from star_amd.optim import FlatAdamW
     from star_amd.synthetic import make_structured_batch
     from star_amd.utils.CoModule import CoModule
 
     torch.manual_seed(0)
-    model = mm.amortized_ind_patch8_light(time_stamp=T, mask_method="complement").to(DEV)
+    model = mm.amortized_ind_patch8_light(time_stamp=T, mask_method="complement").to(DEV).set_compute_dtype(dtype)
     opt = FlatAdamW(model, lr=1e-3, betas=(0.9, 0.95), weight_decay=0.05)
     cm = CoModule(model, opt, "ind_mae")
     model.train()
     batches = [make_structured_batch(B, A, T, seed=100 + i) for i in range(nb)]
+    trail = []
     for it in range(steps):
         opt.param_groups[0]["lr"] = 1.5e-3 * min(1.0, (it + 1) / 40.0) * (0.1 + 0.9 * 0.5 * (1 + np.cos(np.pi * it / steps)))
         torch.manual_seed(1000 + it)
         loss, _, _ = cm.step_mae_completion(batches[it % nb], B, 0.75, trainable=True)
-    return {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}, loss
+        if every and (it + 1) % every == 0:
+            trail.append(float(loss))
+    return {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}, loss, trail
+
+
+# Loss of the float32-mode training run below at steps 75, 150, ..., 1500 (seeds, data and schedule are fixed; measured on MI355X,
+# round 3).  The run is what produces the weights the parity assertions are made on: pinning its trajectory keeps "the weights the
+# test trains" the same object from build to build (float32 kernels differ between builds by summation order only: ~1e-6 per step).
+TRAIN_TRAIL = [0.07595, 0.0575, 0.05314, 0.05452, 0.04438, 0.04278, 0.03844, 0.03464, 0.03448, 0.02964, 0.02652, 0.02283, 0.02334, 0.02181,
+               0.02042, 0.0201, 0.01656, 0.01804, 0.01673, 0.01835]
 
 
 def test_full_size_trained_model_both_modes_against_oracle():
-    """amortized_ind_patch8_light (256 x 256 x 13, L = 1024) trained for 1500 bf16 steps with the HIP path on the structured
-    law (loss 0.81 -> 0.015, median logit margin 12, 1.4 % occupied decisions), then one held-out 3-agent scene: the CPU oracle
-    on the trained weights against HIP fp32 (identical decisions / fused maps / IoU) and HIP bf16 (bounded, see module doc)."""
+    """amortized_ind_patch8_light (256 x 256 x 13, L = 1024) trained for 1500 float32-mode steps with the HIP path on the structured
+    law (loss 0.81 -> 0.015, median logit margin 12, 1.4 % occupied decisions; the loss trajectory is pinned: TRAIN_TRAIL), then one
+    held-out 3-agent scene: the CPU oracle on the trained weights against HIP fp32 and HIP bf16x3 (identical decisions / fused maps /
+    IoU wherever the oracle's margin exceeds the logit error bound) and HIP bf16 (bounded, see module doc)."""
     from star_amd.models import multiagent_mae as mm
     from star_amd.synthetic import make_structured_batch
 
     T = 1
-    sd, last = _train_light(T, 1500, 2, 5, 16)
+    sd, last, trail = _train_light(T, 1500, 2, 5, 16, dtype="fp32", every=75)
+    print("TRAIN_TRAIL =", [round(v, 5) for v in trail])
     assert last < 0.03, last                      # it did learn (all-free prediction sits at 0.06)
+    if TRAIN_TRAIL is not None:
+        np.testing.assert_allclose(trail, TRAIN_TRAIL, rtol=0.03, atol=2e-4)
     data = make_structured_batch(1, 3, T, seed=999, device="cpu")
     bev = data["bev_seq"].squeeze(1).permute(0, 3, 1, 2).contiguous()
     nxt = data["bev_seq_next"]
@@ -158,20 +176,26 @@ def test_full_size_trained_model_both_modes_against_oracle():
     oiou = _iou(ores, teacher)
     ograds = {k: v.grad for k, v in osd.items() if v.grad is not None and v.grad.norm() > 1e-9}
     gall = float(torch.sqrt(sum(g.pow(2).sum() for g in ograds.values())))
-    for dtype in ("fp32", "bf16"):
+    for dtype in ("fp32", "bf16x3", "bf16"):
         m = mm.amortized_ind_patch8_light(time_stamp=T, mask_method="complement")
         m.load_state_dict(sd)
         m = m.to(DEV).set_compute_dtype(dtype)
         m.train()
         m._noise_override = noise.to(DEV)
         m._taps = {}
-        loss, result, latent, ind = m(bev.to(DEV), nxt.to(DEV), None, data["trans_matrices"], data["num_agent"].to(DEV), 1)
-        loss.backward()
+        if dtype == "bf16x3":      # the inference mode: forward() without the autograd edge, the decisions' assertions of the float32 mode
+            with torch.no_grad():
+                loss, result, latent, ind = m(bev.to(DEV), nxt.to(DEV), None, data["trans_matrices"], data["num_agent"].to(DEV), 1)
+        else:
+            loss, result, latent, ind = m(bev.to(DEV), nxt.to(DEV), None, data["trans_matrices"], data["num_agent"].to(DEV), 1)
+            loss.backward()
         pe = (m._taps["pred"].cpu() - opred).abs()
         flips = ind.cpu().numpy() != oind.numpy()
         params = dict(m.named_parameters())
-        rel = {k: float((params[k].grad.cpu() - g).norm() / g.norm()) for k, g in ograds.items()}
-        if dtype == "fp32":
+        rel = {k: float((params[k].grad.cpu() - g).norm() / g.norm()) for k, g in ograds.items()} if dtype != "bf16x3" else {"-": 0.0}
+        print("full size, %s: max |dlogit| %.2e, flips %d, max margin of a flip %.2e" % (
+            dtype, pe.max().item(), int(flips.sum()), float(margin[flips].max()) if flips.any() else 0.0))
+        if dtype in ("fp32", "bf16x3"):
             assert abs(loss.item() - ol.item()) < 1e-6
             assert pe.max().item() < 1e-3                                      # measured 1.2e-4 .. 2.6e-4 at |logit| <= 15
             # identical decisions wherever the oracle's margin exceeds the logit error bound; the weights come out of a bf16
