@@ -47,28 +47,29 @@ def parse():
 
 
 # kernel family (ops.Profiler tag) -> kernel-name prefixes in the rocprofv3 PMC summary committed under profiles/
-_FAMILY_KERNELS = {"gemm_nt": ("void gemm_nt_fast_kernel", "void gemm_nt_wreg_kernel", "void gemm_nt_kernel"), "gemm_wgrad": ("void gemm_tn_", "wgrad_reduce_kernel"), "mlp_fwd": ("void mlp_fwd_kernel",), "gemm_res_ln": ("void gemm_res_ln_kernel",),
+_FAMILY_KERNELS = {"gemm_nt": ("void gemm_nt_fast_kernel", "void gemm_nt_wreg_kernel", "void gemm_nt_kernel"), "gemm_wgrad": ("void gemm_tn_", "wgrad_reduce_kernel"), "gemm_res_ln": ("void gemm_res_ln_kernel",),
                    "attn_fwd": ("void attn_fwd_",), "attn_bwd": ("void attn_bwd_", "void attn_delta_"),
                    "layernorm_fwd": ("void ln_fwd_",), "layernorm_bwd": ("void ln_bwd_", "ln_bwd_reduce"),
-                   "ce_argmax": ("void ce_argmax_",), "warp_fuse": ("warp_fuse_", "wf_pack_bits")}
+                   "ce_argmax": ("void ce_argmax_",), "warp_fuse": ("warp_fuse_", "wf_pack_bits"), "patchify": ("void patchify_kernel",)}
 
 
 def _pmc_file(name, workload):
     """A committed PMC summary (tools/pmc_traffic.sh / tools/pmc_mfma.sh over this same bench command), or None when it is
     absent or was collected for a DIFFERENT workload string: counters cannot be collected inside the timed run, so they are
     read from profiles/ -- but only for the workload they were measured on."""
-    path = os.path.join(ROOT, "profiles", name)
-    if not os.path.exists(path):
-        return None
-    with open(path) as f:
-        d = json.load(f)
-    return d if d.get("workload") == workload else None
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", name)), reverse=True):     # newest round first
+        with open(path) as f:
+            d = json.load(f)
+        if d.get("workload") == workload:
+            return d
+    return None
 
 
 def _pmc_traffic(family, workload):
     """HBM-side bytes per launch of the family's kernels (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, gfx950
     FETCH_SIZE correction applied)."""
-    d = _pmc_file("r02_pmc_traffic.json", workload)
+    d = _pmc_file("r*_pmc_traffic.json", workload)
     if d is None or family not in _FAMILY_KERNELS:
         return None
     tot, n = 0.0, 0
@@ -81,7 +82,7 @@ def _pmc_traffic(family, workload):
 
 def _pmc_mfma_util(family, workload):
     """Fraction of SIMD cycles with the MFMA pipe busy for the family (one more --pmc pass)."""
-    d = _pmc_file("r02_pmc_mfma.json", workload)
+    d = _pmc_file("r*_pmc_mfma.json", workload)
     if d is None:
         return None
     v = d["families"].get(family)
@@ -103,15 +104,36 @@ def flops_per_frame(c, mask, mask_ratio, train):
     return (T * enc + dec) * (3 if train else 1)
 
 
-def _cpu_model():
+def _cpu_info():
+    """(model string, physical cores of the whole machine) from lscpu, /proc/cpuinfo as the fallback (report both)."""
+    import subprocess
+    model, cores = "unknown", None
     try:
-        with open("/proc/cpuinfo") as f:
-            for line in f:
-                if line.startswith("model name"):
-                    return line.split(":", 1)[1].strip()
-    except OSError:
+        out = subprocess.run(["lscpu"], capture_output=True, text=True, timeout=10).stdout
+        f = {k.strip(): v.strip() for k, v in (line.split(":", 1) for line in out.splitlines() if ":" in line)}
+        model = f.get("Model name", model)
+        if "Core(s) per socket" in f and "Socket(s)" in f:
+            cores = int(f["Core(s) per socket"]) * int(f["Socket(s)"])
+    except Exception:
         pass
-    return "unknown"
+    if model == "unknown" or cores is None:
+        try:
+            seen = set()
+            phys = core = None
+            with open("/proc/cpuinfo") as fh:
+                for line in fh:
+                    if line.startswith("model name") and model == "unknown":
+                        model = line.split(":", 1)[1].strip()
+                    elif line.startswith("physical id"):
+                        phys = line.split(":", 1)[1].strip()
+                    elif line.startswith("core id"):
+                        core = line.split(":", 1)[1].strip()
+                        seen.add((phys, core))
+            if cores is None and seen:
+                cores = len(seen)
+        except OSError:
+            pass
+    return model, cores
 
 
 def cpu_baseline(args, cores, budget_s=100.0):
@@ -163,8 +185,11 @@ def cpu_baseline(args, cores, budget_s=100.0):
     t_train, n_train = timed(train_step)
     t_inf, n_inf = timed(infer_step)
     leg = "train" if args.mode == "train" else "infer"
+    cpu_model, phys = _cpu_info()
     return {"value": round(args.agents / (t_train if leg == "train" else t_inf), 3), "unit": "BEV frames/s", "cores": cores, "kind": "port",
-            "cpu_model": _cpu_model(), "train_frames_per_s": round(args.agents / t_train, 3), "infer_frames_per_s": round(args.agents / t_inf, 3),
+            "cpu_model": cpu_model, "machine_physical_cores": phys, "machine_logical_cpus": os.cpu_count(),
+            "cores_note": "cores = threads used = the box's CPU share for one GPU (its OMP_NUM_THREADS); the machine's own core count is beside it",
+            "train_frames_per_s": round(args.agents / t_train, 3), "infer_frames_per_s": round(args.agents / t_inf, 3),
             "sample": "CPU oracle (fp32 PyTorch-CPU, %d threads), 1 scene x %d agents: training step incl. AdamW (median of %d after 3 "
                       "warm-up) and inference = config C1 (median of %d after 3 warm-up); value = the %s leg"
                       % (cores, args.agents, n_train, n_inf, leg)}
@@ -324,7 +349,12 @@ def main():
             "step_roofline": {"gflop_per_frame": round(fpf / 1e9, 2), "achieved_tflops": round(value * fpf / 1e12 / world, 1),
                               "peak_tflops": peak_f, "frac_of_mfma_peak": round(value * fpf / 1e12 / world / peak_f, 4)},
             "families": families[:6],
+            # north star: achieved HBM GB/s of the gather / warp / fusion path -- its families whatever their share of the step
+            # (bytes = what each launch moves in its own operand formats, star_amd/ops.py; HIP events of the probe step)
+            "bandwidth_path": [f_ for f_ in families if f_["kernel"] in ("ce_argmax", "warp_fuse", "patchify", "layernorm_fwd", "layernorm_bwd")],
         }
+        for f_ in out["bandwidth_path"]:
+            f_["traffic"] = _pmc_traffic(f_["kernel"], workload)
         if world == 1 and not args.no_cpu_baseline and args.com == "ind_mae":
             out["cpu_baseline"] = cpu_baseline(args, min(16, os.cpu_count() or 1))
         print(json.dumps(out), flush=True)

@@ -100,6 +100,8 @@ typedef struct StarLnFoldJob {
     int32_t nb;      /* star_layernorm_fold_rows(M) of the call that filled ws */
     int32_t D;
 } StarLnFoldJob;
+/* max_D must be the LARGEST D over the jobs (it sizes the grid: a smaller value leaves columns of the wider jobs unwritten);
+ * a job's dgamma or dbeta may be NULL (that half is skipped). */
 int star_layernorm_fold_rows(int M);
 int star_layernorm_fold_batch(const StarLnFoldJob* jobs, int njobs, int max_D, void* stream);
 
@@ -108,7 +110,9 @@ int star_layernorm_fold_batch(const StarLnFoldJob* jobs, int njobs, int max_D, v
  * that forbid hipMalloc).  Same kernels and results, bit for bit; the partial dgamma/dbeta rows live in a 6 MiB
  * file-scope device array of the library (one copy per GPU, held until the process ends) instead of `ws`.
  * Limit: D <= 1024 (a larger D is rejected with an error; use star_layernorm_bwd).  Every call on a GPU shares that
- * GPU's array: calls that overlap on one GPU (two streams, two threads) race. */
+ * GPU's array: calls that overlap on one GPU (two streams, two threads) race.  The FIRST call on each device looks the array's
+ * address up (hipGetSymbolAddress, which may load the code object) and is therefore not capture-safe: make one call per device
+ * outside stream capture before using it under a graph. */
 int star_layernorm_bwd_static(const void* dy, const float* x, const float* gamma, const float* mean,
                               const float* rstd, const float* g_in, float* g_out, void* g_out_lp, float* dgamma,
                               float* dbeta, int M, int D, int dt, void* stream);
@@ -192,17 +196,6 @@ int star_gemm_res_ln(const void* A, const void* W, const float* bias, const floa
                      const float* beta, float eps, void* h, float* mean, float* rstd, int M, int N, int K, int dt,
                      void* stream);
 
-/* ---- K3': the block's MLP forward as one kernel ---------------------------------------------------------
- * Replaces timm 0.3.2 Mlp.forward plus the block's second residual add (Block.forward: x = x + mlp(norm2(x)); ctor
- * mae_base.py:279-281,308-310): xout[M, D] (float32) = xres + fc2(gelu(fc1(h))) with h [M, D], w1 [HID, D], w2 [D, HID] in bf16
- * (the Linear weights as they lie in memory), b1 [HID], b2 [D] float32.  xout may be xres.  Training: v_out / g_out [M, HID]
- * bf16 receive gelu(u) and gelu'(u) (what the backward reads); inference: both NULL.  The hidden activations stay on chip.
- * star_mlp_fwd_supported(D, HID, dt) != 0 tells whether a kernel exists for the shape (bf16, D = 256 or 384, HID % 32 == 0,
- * HID <= 2048); other shapes -> error (callers use two star_gemm launches instead). */
-int star_mlp_fwd_supported(int D, int HID, int dt);
-int star_mlp_fwd(const void* h, const void* w1, const float* b1, const void* w2, const float* b2, const float* xres,
-                 float* xout, void* v_out, void* g_out, int M, int D, int HID, int dt, void* stream);
-
 /* ---- K4: attention -----------------------------------------------------------------------------------
  * Replaces timm Attention.forward between qkv and proj: softmax(q k^T hd^-0.5) v, no mask, no
  * dropout.  qkv [NB, L, 3, H, hd] in `dt` (the qkv Linear output as it lies in memory), out
@@ -212,13 +205,6 @@ int star_attn_fwd(const void* qkv, void* out, float* lse, int NB, int L, int H, 
 /* dqkv [NB, L, 3, H, hd] from dout [NB, L, H*hd]; delta float32 [2, NB, H, L] is workspace. */
 int star_attn_bwd(const void* qkv, const void* out, const void* dout, const float* lse, float* delta,
                   void* dqkv, int NB, int L, int H, int hd, int dt, void* stream);
-/* The same gradient (the autograd backward of timm Attention.forward, mae_base.py:279-281) with a workspace the library
- * sizes: ws float32 of star_attn_bwd_ws_bytes(...) bytes.  bf16 with hd <= 32 runs ONE kernel that sweeps the scores once
- * for dQ, dK and dV (dK / dV bit-identical to star_attn_bwd; dQ sums its keys in another, fixed order); every other
- * case runs star_attn_bwd's kernels.  ws_bytes smaller than required -> error. */
-int64_t star_attn_bwd_ws_bytes(int NB, int L, int H, int hd, int dt);
-int star_attn_bwd_ws(const void* qkv, const void* out, const void* dout, const float* lse, float* ws, int64_t ws_bytes,
-                     void* dqkv, int NB, int L, int H, int hd, int dt, void* stream);
 
 /* ---- K1: voxel -> patch gather ------------------------------------------------------------------------
  * Replaces the im2col half of Conv2d(13, D, k=p, s=p) + flatten(2).transpose(1,2) (timm PatchEmbed;

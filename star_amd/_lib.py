@@ -62,10 +62,6 @@ _SIGS = {
     "star_gemm_res_ln_supported": (C.c_int, [_I, _I, _I]),
     "star_gemm_res_ln_prefers": (C.c_int, [_I, _I, _I, _I]),
     "star_gemm_res_ln": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, C.c_float, _P, _P, _P, _I, _I, _I, _I, _P]),
-    "star_mlp_fwd_supported": (C.c_int, [_I, _I, _I]),
-    "star_mlp_fwd": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
-    "star_attn_bwd_ws_bytes": (C.c_int64, [_I, _I, _I, _I, _I]),
-    "star_attn_bwd_ws": (C.c_int, [_P, _P, _P, _P, _P, C.c_int64, _P, _I, _I, _I, _I, _I, _P]),
     "star_patchify": (C.c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "star_ce_nblocks": (C.c_int, [_I, _I, _I, _I]),
     "star_ce_argmax": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),

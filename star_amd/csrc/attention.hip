@@ -521,8 +521,7 @@ __global__ void attn_delta_kernel(const T* __restrict__ out, const T* __restrict
 }
 
 
-// sum_j o[j] * d[j] over 8 bf16 pairs as one fma chain in element order: the dQ kernel (which folds the row dots into its
-// prologue) and attn_delta_bf16_kernel (the fused backward's table pass) follow the same operation sequence, bit for bit:
+// sum_j o[j] * d[j] over 8 bf16 pairs as one fma chain in element order (the dQ kernel folds the row dots into its prologue):
 // half0 = chain over elements 16 ks + 0..7 (ks ascending), half1 = chain over 16 ks + 8..15, dot = half0 + half1
 __device__ __forceinline__ float attn_dot8(uint4 o, uint4 d, float acc) {
     const unsigned x[4] = {o.x, o.y, o.z, o.w}, y[4] = {d.x, d.y, d.z, d.w};
@@ -534,47 +533,6 @@ __device__ __forceinline__ float attn_dot8(uint4 o, uint4 d, float acc) {
     return acc;
 }
 
-// bf16 path of the same, coalesced on both sides: a block takes 64 consecutive rows of one sequence, reads them as they lie
-// in memory (a thread = one (row, head) = HD bf16 of O and dO in 16-byte loads, all in flight), transposes the sums through
-// LDS and writes [head][row] runs of 256 bytes (the per-thread version scattered 4-byte stores L*4 bytes apart).
-template <int HD>
-__global__ __launch_bounds__(256) void attn_delta_bf16_kernel(const bf16_t* __restrict__ out, const bf16_t* __restrict__ dout,
-                                                              const float* __restrict__ lse, float* __restrict__ ws, int NB, int L, int H,
-                                                              float inv_c) {
-    extern __shared__ float dl_tile[];   // [H][65]
-    const int blocks_per_seq = (L + 63) / 64;
-    const int nb = blockIdx.x / blocks_per_seq, l0 = (blockIdx.x % blocks_per_seq) * 64;
-    const int rows = min(64, L - l0);
-    const int64_t total = (int64_t)NB * L * H;
-    for (int i = threadIdx.x; i < rows * H; i += 256) {
-        const int r = i / H, h = i - r * H;
-        const int64_t base = ((int64_t)nb * L + l0 + r) * H * HD + h * HD;
-        uint4 a[HD / 8], b[HD / 8];
-#pragma unroll
-        for (int j = 0; j < HD / 8; ++j) {
-            a[j] = *reinterpret_cast<const uint4*>(out + base + j * 8);
-            b[j] = *reinterpret_cast<const uint4*>(dout + base + j * 8);
-        }
-        float half0 = 0.f, half1 = 0.f;
-#pragma unroll
-        for (int j = 0; j < HD / 8; j += 2) {
-            half0 = attn_dot8(a[j], b[j], half0);
-            half1 = attn_dot8(a[j + 1], b[j + 1], half1);
-        }
-        dl_tile[h * 65 + r] = half0 + half1;
-    }
-    __syncthreads();
-    for (int j = threadIdx.x; j < H * 64; j += 256) {
-        const int h = j >> 6, r = j & 63;
-        if (r >= rows) continue;
-        const int64_t o = ((int64_t)nb * H + h) * L + l0 + r;
-        ws[o] = -dl_tile[h * 65 + r];
-        ws[total + o] = -lse[o] * inv_c;
-    }
-}
-
-// dQ: query on the lane (the forward's skeleton and ring).  Stage = K image | V image; K is read by rows for S
-// and transposed for dQ^T += K^T dS^T from the same image.  Keys past L need no mask: their K rows are zero.
 template <int HD>
 __global__ __launch_bounds__(AT) void attn_bwd_dq_bf16_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ out,
                                                               const bf16_t* __restrict__ dout, const float* __restrict__ lse,
@@ -862,303 +820,6 @@ __global__ __launch_bounds__(AT) void attn_bwd_dkv_bf16_kernel(const bf16_t* __r
 }
 
 // ------------------------------------------------------------------------------------------------------
-// Fused backward (hd <= 32): ONE sweep over the scores yields dQ, dK and dV -- S, dP, the exponentials and dS are computed
-// once instead of once per kernel.  A workgroup of 8 waves owns one (sequence, head); a wave owns 64 keys (two 32-key blocks,
-// K / V fragments and the dK / dV accumulators in registers), so the workgroup covers 512 keys per pass and sweeps the queries
-// in the dK/dV kernel's ring (stage = Q image | dO image | row constants).  What the fusion adds per (32 queries x 32 keys):
-//   * dS (key on the lane, as the accumulator holds it) goes bf16 through a wave-private [key][query] LDS image (72-byte rows:
-//     conflict-free 8-byte stores) and comes back query-on-the-lane by ds_read_b64_tr_b16 as the B operand of
-//     dQ^T[d][q] += K^T[d][key] dS^T[key][q]; K^T fragments live in registers for the pass.
-//   * the 8 waves' partial dQ^T tiles (their 64 keys each) meet in LDS (double-buffered, one barrier per 32 queries) and waves
-//     4-7 add them in wave order -> bitwise reproducible, no atomics.  L > 512: passes over the key range; the fp32 dQ partial
-//     of a pass rests in `dq_part` and is picked up by the SAME thread in the next pass.
-//   * waves 0-3 issue every LDS-DMA and nothing else that counts in vmcnt inside the ring; waves 4-7 own the global stores of
-//     the loop, so the ring's counted vmcnt never sees a store.
-#define FB 512
-template <int HD>
-__global__ __launch_bounds__(FB) void attn_bwd_fused_bf16_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout,
-                                                                 const float* __restrict__ nlsc, const float* __restrict__ ndelta,
-                                                                 bf16_t* __restrict__ dqkv, float* __restrict__ dq_part, int L, int H, float c,
-                                                                 float scale) {
-    using C = ACfg<HD>;
-    static_assert(HD == 16 || HD == 32, "fused backward: hd 16 / 32");
-    constexpr int NI = 2 * C::NP / 4;
-    constexpr int STAGE = 2 * C::TILE + 512;
-    constexpr int DSROW = 72, DSIMG = 32 * DSROW;          // dS image: [key 32][query 32] bf16, 8 bytes of padding per row
-    constexpr int RROW = HD + 4, RWAVE = 32 * RROW * 4;    // dQ partial of a wave: [query 32][d HD + 4] f32
-    constexpr int OFF_DS = 3 * STAGE, OFF_RED = OFF_DS + 8 * DSIMG;
-    constexpr int EPT = HD / 8;                            // dQ elements per reducing thread (256 threads x EPT = 32 x HD)
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int h = blockIdx.x % H, nb = blockIdx.x / H;
-    const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h2 = lane >> 5;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const bool loader = wave < 4;
-    const int64_t rs = (int64_t)3 * H * HD, ro = (int64_t)H * HD;
-    const bf16_t* qb = qkv + (int64_t)nb * L * rs + h * HD;
-    const bf16_t* dob = dout + (int64_t)nb * L * ro + h * HD;
-
-    __amdgpu_buffer_rsrc_t rsq = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(qb), 0, (unsigned)((L * rs - h * HD) * 2), 0x00020000);
-    __amdgpu_buffer_rsrc_t rsd = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(dob), 0, (unsigned)((L * ro - h * HD) * 2), 0x00020000);
-    const float* cst = ((wave & 1) ? ndelta : nlsc) + ((int64_t)nb * H + h) * L;
-    __amdgpu_buffer_rsrc_t rsc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(cst), 0, (unsigned)(L * 4), 0x00020000);
-    unsigned src[NI];
-    int dst[NI];
-    bool isd[NI];
-#pragma unroll
-    for (int j = 0; j < NI; ++j) {
-        const int p = j * 4 + (wave & 3);
-        isd[j] = p >= C::NP;
-        const int pp = isd[j] ? p - C::NP : p;
-        src[j] = dma_src<HD>(pp, lane, (isd[j] ? ro : rs) * 2);
-        dst[j] = isd[j] * C::TILE + pp * 1024;
-    }
-    const unsigned step_q = (unsigned)(64 * rs * 2), step_d = (unsigned)(64 * ro * 2);
-    const int cdst = 2 * C::TILE + (wave & 1) * 256;
-    auto issue = [&](int t, int stage) {
-        unsigned char* sb = smem + stage * STAGE;
-#pragma unroll
-        for (int j = 0; j < NI; ++j) {
-            if (isd[j]) dma16(rsd, sb + dst[j], src[j] + (unsigned)t * step_d);
-            else dma16(rsq, sb + dst[j], src[j] + (unsigned)t * step_q);
-        }
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsc, (lds_ptr_t)(sb + cdst), 4, (unsigned)((t * 64 + lane) * 4), 0, 0, 0);
-    };
-
-    int koff[C::KS];
-#pragma unroll
-    for (int ks = 0; ks < C::KS; ++ks) koff[ks] = row_off<HD>(r, ks * 2 + h2);
-    const int g = lane >> 4, i16 = lane & 15;
-    int toff[2];
-#pragma unroll
-    for (int u = 0; u < 2; ++u)
-        toff[u] = tr_off<HD>(4 * (g >> 1) + (i16 >> 2) + 8 * u, ((HD >= 32 ? (g & 1) : 0) * 16 + 4 * (i16 & 3)) * 2);
-
-    const unsigned lds_base = lds_u32(smem);
-    const unsigned ds_wr = lds_base + OFF_DS + wave * DSIMG + r * DSROW + 8 * h2;                                    // + 16 t
-    const unsigned ds_rd = lds_base + OFF_DS + wave * DSIMG + (8 * h2 + (i16 >> 2)) * DSROW + 32 * (g & 1) + 8 * (i16 & 3);   // + 1152 s2, + 288
-    // the partial tiles are written and read by asm LDS instructions: a compiler-visible LDS access after an LDS-DMA makes hipcc
-    // wait for vmcnt(0), which would drain the ring (loaders) or stall on the loop's own global stores (reducers)
-    const unsigned red_wr = lds_base + OFF_RED + wave * RWAVE + (r * RROW + 4 * h2) * 4;                              // + 32 t, + buffer
-    const int rt = tid - 256, rq = rt >> 3, rd0 = (rt & 7) * EPT;                                                      // reducing threads (waves 4-7)
-    const unsigned red_rd = lds_base + OFF_RED + (rq * RROW + rd0) * 4;
-    const int nt = (L + 63) / 64, npass = (L + 511) / 512;
-
-    for (int pass = 0; pass < npass; ++pass) {
-        const int k0 = pass * 512 + wave * 64;
-        short8_t kf[2][C::KS], vf[2][C::KS], ktf[2][2];
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
-            const int key = k0 + kb * 32 + r;
-#pragma unroll
-            for (int ks = 0; ks < C::KS; ++ks) {
-                kf[kb][ks] = vf[kb][ks] = (short8_t){0, 0, 0, 0, 0, 0, 0, 0};
-                if (key < L) {
-                    kf[kb][ks] = *reinterpret_cast<const short8_t*>(qb + H * HD + (int64_t)key * rs + ks * 16 + 8 * h2);
-                    vf[kb][ks] = *reinterpret_cast<const short8_t*>(qb + 2 * H * HD + (int64_t)key * rs + ks * 16 + 8 * h2);
-                }
-            }
-            // K^T fragments, natural k order: lane = row d, element j = key 16 s2 + 8 h2 + j of the block
-#pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2) {
-                // unconditional (clamped) loads, masked afterwards: all 32 of a pass are in flight together
-                short8_t t;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const int kk = k0 + kb * 32 + s2 * 16 + 8 * h2 + j;
-                    const unsigned short v = qb[H * HD + (int64_t)min(kk, L - 1) * rs + (r & (HD - 1))];
-                    t[j] = (r < HD && kk < L) ? (short)v : (short)0;
-                }
-                ktf[kb][s2] = t;
-            }
-        }
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
-#pragma unroll
-            for (int ks = 0; ks < C::KS; ++ks) {
-                pin(kf[kb][ks]);
-                pin(vf[kb][ks]);
-            }
-            pin(ktf[kb][0]);
-            pin(ktf[kb][1]);
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // incl. the previous pass's stores: the ring counts loads only
-        __syncthreads();                                    // the previous pass's staging rows have been read
-
-        f32x16_t dk[2], dv[2];
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) dk[kb][e] = dv[kb][e] = 0.f;
-
-        // sum of the 8 waves' dQ partials of query block m (waves 4-7), carried across passes in dq_part
-        auto reduce = [&](int m) {
-            if (loader) return;
-            const int qg = m * 32 + rq;
-            float* pp = dq_part + (((int64_t)nb * H + h) * L + min(qg, L - 1)) * HD + rd0;
-            float prev[EPT];                               // the previous passes' sum: requested before the LDS reads
-#pragma unroll
-            for (int e = 0; e < EPT; ++e) prev[e] = pass > 0 ? pp[e] : 0.f;
-            float acc[EPT];
-#pragma unroll
-            for (int e = 0; e < EPT; ++e) acc[e] = 0.f;
-            const unsigned ra = red_rd + (m & 1) * 8 * RWAVE;
-            if constexpr (EPT == 4) {
-                f32x4_t v[8] = {lds_f4<0>(ra), lds_f4<RWAVE>(ra), lds_f4<2 * RWAVE>(ra), lds_f4<3 * RWAVE>(ra),
-                                lds_f4<4 * RWAVE>(ra), lds_f4<5 * RWAVE>(ra), lds_f4<6 * RWAVE>(ra), lds_f4<7 * RWAVE>(ra)};
-                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]));
-#pragma unroll
-                for (int w = 0; w < 8; ++w)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) acc[e] += v[w][e];
-            } else {
-                f32x2_t v[8] = {lds_f2<0>(ra), lds_f2<RWAVE>(ra), lds_f2<2 * RWAVE>(ra), lds_f2<3 * RWAVE>(ra),
-                                lds_f2<4 * RWAVE>(ra), lds_f2<5 * RWAVE>(ra), lds_f2<6 * RWAVE>(ra), lds_f2<7 * RWAVE>(ra)};
-                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]));
-#pragma unroll
-                for (int w = 0; w < 8; ++w)
-#pragma unroll
-                    for (int e = 0; e < 2; ++e) acc[e] += v[w][e];
-            }
-            if (qg < L) {
-#pragma unroll
-                for (int e = 0; e < EPT; ++e) acc[e] += prev[e];
-                if (pass + 1 < npass) {
-#pragma unroll
-                    for (int e = 0; e < EPT; ++e) pp[e] = acc[e];
-                } else {
-                    bf16_t* o = dqkv + ((int64_t)nb * L + qg) * rs + h * HD + rd0;
-                    unsigned w[EPT / 2];
-#pragma unroll
-                    for (int e = 0; e < EPT / 2; ++e) w[e] = (unsigned)f2bf(acc[2 * e] * scale) | ((unsigned)f2bf(acc[2 * e + 1] * scale) << 16);
-                    if constexpr (EPT == 4) *reinterpret_cast<uint2*>(o) = make_uint2(w[0], w[1]);
-                    else *reinterpret_cast<unsigned*>(o) = w[0];
-                }
-            }
-        };
-
-        if (loader) {
-            issue(0, 0);
-            if (nt > 1) issue(1, 1);
-        }
-        int stage = 0;
-        for (int it = 0; it < nt; ++it) {
-            if (loader) {
-                if (it + 1 < nt) wait_vm<NI + 1>(); else wait_vm<0>();
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's dQ partial of the previous query block is in LDS
-            __builtin_amdgcn_s_barrier();
-            asm volatile("" ::: "memory");
-            if (loader && it + 2 < nt) issue(it + 2, stage >= 1 ? stage - 1 : 2);
-            const unsigned char* ql = smem + stage * STAGE;
-            const unsigned char* dol = ql + C::TILE;
-            const unsigned sbase = lds_base + stage * STAGE;
-            stage = stage == 2 ? 0 : stage + 1;
-
-#pragma unroll
-            for (int qblk = 0; qblk < 2; ++qblk) {
-                const int n = it * 2 + qblk;
-                if (qblk == 1) {
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                    __builtin_amdgcn_s_barrier();
-                    asm volatile("" ::: "memory");
-                }
-                if (n > 0) reduce(n - 1);
-
-                // transposed Q / dO fragments of this 32-query block (A operands of dK / dV), shared by both key blocks
-                short4_t qlo[2], qhi[2], dlo[2], dhi[2];
-                {
-                    const unsigned hb = sbase + qblk * 32 * C::RB;
-                    tr_issue_half<C::RB>(hb + toff[0], hb + toff[1], qlo, qhi);
-                    tr_issue_half<C::RB>(hb + C::TILE + toff[0], hb + C::TILE + toff[1], dlo, dhi);
-                }
-                short8_t qa[C::KS], da[C::KS];
-#pragma unroll
-                for (int ks = 0; ks < C::KS; ++ks) {
-                    qa[ks] = *reinterpret_cast<const short8_t*>(ql + koff[ks] + qblk * 32 * C::RB);
-                    da[ks] = *reinterpret_cast<const short8_t*>(dol + koff[ks] + qblk * 32 * C::RB);
-                }
-                f32x16_t dq;
-#pragma unroll
-                for (int e = 0; e < 16; ++e) dq[e] = 0.f;
-                const unsigned ca = sbase + 2 * C::TILE + (qblk * 32 + 4 * h2) * 4;
-#pragma unroll
-                for (int kb = 0; kb < 2; ++kb) {
-                    f32x16_t s, dp;
-                    {
-                        const f32x4_t l0 = lds_f4<0>(ca), l1 = lds_f4<32>(ca), l2 = lds_f4<64>(ca), l3 = lds_f4<96>(ca);
-                        const f32x4_t d0 = lds_f4<256>(ca), d1 = lds_f4<288>(ca), d2 = lds_f4<320>(ca), d3 = lds_f4<352>(ca);
-                        s = __builtin_shufflevector(__builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7),
-                                                    __builtin_shufflevector(l2, l3, 0, 1, 2, 3, 4, 5, 6, 7), 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15);
-                        dp = __builtin_shufflevector(__builtin_shufflevector(d0, d1, 0, 1, 2, 3, 4, 5, 6, 7),
-                                                     __builtin_shufflevector(d2, d3, 0, 1, 2, 3, 4, 5, 6, 7), 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15);
-                        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(s), "+v"(dp));
-                    }
-#pragma unroll
-                    for (int ks = 0; ks < C::KS; ++ks) {
-                        s = mfma32(qa[ks], kf[kb][ks], s);
-                        dp = mfma32(da[ks], vf[kb][ks], dp);
-                    }
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) {
-                        s[e] = __builtin_amdgcn_exp2f(s[e] * c);
-                        dp[e] *= s[e];
-                    }
-                    if (kb == 0) tr_wait_half(qlo, qhi, dlo, dhi);
-                    bf16x8_t dsf[2];
-#pragma unroll
-                    for (int s2 = 0; s2 < 2; ++s2) {
-                        const bf16x8_t pf = cvt8(s, s2);
-                        dsf[s2] = cvt8(dp, s2);
-                        dv[kb] = mfma32(join8(dlo[s2], dhi[s2]), pf, dv[kb]);
-                        dk[kb] = mfma32(join8(qlo[s2], qhi[s2]), dsf[s2], dk[kb]);
-                    }
-                    // dS -> [key][query] image (registers 4t..4t+3 = queries 8t + 4 h2 ..+3 of this lane's key), back transposed
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) {
-                        typedef __attribute__((ext_vector_type(4))) unsigned u4;
-                        const u4 w = __builtin_bit_cast(u4, dsf[t >> 1]);
-                        typedef __attribute__((ext_vector_type(2))) unsigned u2;
-                        const u2 d2 = (u2){w[(t & 1) * 2], w[(t & 1) * 2 + 1]};
-                        if (t == 0) asm volatile("ds_write_b64 %0, %1" :: "v"(ds_wr), "v"(d2));
-                        else if (t == 1) asm volatile("ds_write_b64 %0, %1 offset:16" :: "v"(ds_wr), "v"(d2));
-                        else if (t == 2) asm volatile("ds_write_b64 %0, %1 offset:32" :: "v"(ds_wr), "v"(d2));
-                        else asm volatile("ds_write_b64 %0, %1 offset:48" :: "v"(ds_wr), "v"(d2));
-                    }
-                    short4_t tlo[2], thi[2];
-                    tlo[0] = tr16<0>(ds_rd);    thi[0] = tr16<288>(ds_rd);
-                    tlo[1] = tr16<1152>(ds_rd); thi[1] = tr16<1440>(ds_rd);
-                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(tlo[0]), "+v"(thi[0]), "+v"(tlo[1]), "+v"(thi[1]));
-#pragma unroll
-                    for (int s2 = 0; s2 < 2; ++s2) dq = mfma32(ktf[kb][s2], join8(tlo[s2], thi[s2]), dq);
-                }
-                // this wave's partial dQ^T (its 64 keys): registers 4t..4t+3 = d 8t + 4 h2 ..+3 of query r
-                const unsigned rw = red_wr + qblk * 8 * RWAVE;   // buffer n & 1 = qblk
-                // the compiler does not see that the asm stores read an MFMA result: the wait states of that hazard by hand
-                asm volatile("s_nop 15\n\ts_nop 7" : "+v"(dq));
-                lds_w4<0>(rw, (f32x4_t){dq[0], dq[1], dq[2], dq[3]});
-                lds_w4<32>(rw, (f32x4_t){dq[4], dq[5], dq[6], dq[7]});
-                if constexpr (HD == 32) {
-                    lds_w4<64>(rw, (f32x4_t){dq[8], dq[9], dq[10], dq[11]});
-                    lds_w4<96>(rw, (f32x4_t){dq[12], dq[13], dq[14], dq[15]});
-                }
-            }
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __syncthreads();
-        reduce(2 * nt - 1);
-        __syncthreads();                                    // the partials have been read: their region stages the dK / dV rows
-        bf16_t* dkb = dqkv + ((int64_t)nb * L + k0) * rs + H * HD + h * HD;
-        unsigned char* stg = smem + OFF_RED + wave * 4 * 32 * C::RB;
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
-            f32x16_t a1[1] = {dk[kb]}, a2[1] = {dv[kb]};
-            store_T<HD>(a1, scale, stg + (2 * kb) * 32 * C::RB, dkb + (int64_t)kb * 32 * rs, rs, L - k0 - kb * 32, lane);
-            store_T<HD>(a2, 1.0f, stg + (2 * kb + 1) * 32 * C::RB, dkb + (int64_t)kb * 32 * rs + H * HD, rs, L - k0 - kb * 32, lane);
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------------------
 // fp32 path: vector-ALU flash attention, one query per lane; K/V tiles of 32 rows broadcast from LDS.
 #define FT 128
 template <int HD>
@@ -1352,17 +1013,6 @@ static int bwd_bf16(const void* qkv, const void* out, const void* dout, const fl
     return 0;
 }
 template <int HD>
-static int bwd_fused_bf16(const void* qkv, const void* dout, const float* ws, float* dq_part, void* dqkv, int NB, int L, int H, float c,
-                          float scale, hipStream_t s) {
-    const float* delta = ws;                           // negated
-    const float* nlsc = ws + (int64_t)NB * H * L;
-    const size_t lds = 3 * (2 * ACfg<HD>::TILE + 512) + 8 * 32 * 72 + 2 * 8 * 32 * (HD + 4) * 4;
-    if (int rc = set_lds(attn_bwd_fused_bf16_kernel<HD>, lds)) return rc;
-    hipLaunchKernelGGL(attn_bwd_fused_bf16_kernel<HD>, dim3(H * NB), dim3(FB), lds, s, (const bf16_t*)qkv, (const bf16_t*)dout, nlsc, delta,
-                       (bf16_t*)dqkv, dq_part, L, H, c, scale);
-    return 0;
-}
-template <int HD>
 static void fwd_f32(const void* qkv, void* out, float* lse, int NB, int L, int H, float c, hipStream_t s) {
     hipLaunchKernelGGL(attn_fwd_f32_kernel<HD>, dim3(cdiv(L, FT), H, NB), dim3(FT), 0, s, (const float*)qkv, (float*)out, lse, L, H, c);
 }
@@ -1408,39 +1058,9 @@ extern "C" int star_attn_fwd(const void* qkv, void* out, float* lse, int NB, int
     return 0;
 }
 
-// Workspace of star_attn_bwd_ws in bytes: the two row-constant tables of star_attn_bwd, plus -- bf16, hd <= 32, L > 512 -- the
-// fp32 dQ partial the fused kernel carries from one 512-key pass to the next.
-static int64_t attn_bwd_ws_floats(int NB, int L, int H, int hd, int dt) {
-    int64_t n = 2 * (int64_t)NB * H * L;
-    if (dt == STAR_BF16 && hd <= 32 && L > 512) n += (int64_t)NB * H * L * hd;
-    return n;
-}
-extern "C" int64_t star_attn_bwd_ws_bytes(int NB, int L, int H, int hd, int dt) {
-    if (NB <= 0 || L <= 0 || H <= 0) return 0;
-    return attn_bwd_ws_floats(NB, L, H, hd, dt) * 4;
-}
-
-static int attn_bwd_impl(const void* qkv, const void* out, const void* dout, const float* lse, float* delta, float* dq_part, void* dqkv,
-                         int NB, int L, int H, int hd, int dt, void* stream);
 
 extern "C" int star_attn_bwd(const void* qkv, const void* out, const void* dout, const float* lse, float* delta, void* dqkv,
                              int NB, int L, int H, int hd, int dt, void* stream) {
-    return attn_bwd_impl(qkv, out, dout, lse, delta, nullptr, dqkv, NB, L, H, hd, dt, stream);
-}
-
-extern "C" int star_attn_bwd_ws(const void* qkv, const void* out, const void* dout, const float* lse, float* ws, int64_t ws_bytes, void* dqkv,
-                                int NB, int L, int H, int hd, int dt, void* stream) {
-    STAR_CHECK(ws != nullptr, "star_attn_bwd_ws: null workspace");
-    if (int rc = attn_check("star_attn_bwd_ws", NB, L, H, hd, dt)) return rc;
-    STAR_CHECK(dt != STAR_BF16X3, "star_attn_bwd_ws: STAR_BF16X3 is a forward-only storage type");
-    STAR_CHECK(ws_bytes >= attn_bwd_ws_floats(NB, L, H, hd, dt) * 4, "star_attn_bwd_ws: workspace of %lld bytes, %lld needed (star_attn_bwd_ws_bytes)",
-               (long long)ws_bytes, (long long)(attn_bwd_ws_floats(NB, L, H, hd, dt) * 4));
-    return attn_bwd_impl(qkv, out, dout, lse, ws, ws + 2 * (int64_t)NB * H * L, dqkv, NB, L, H, hd, dt, stream);
-}
-
-// dq_part != nullptr selects the fused kernel where it exists (bf16, hd <= 32)
-static int attn_bwd_impl(const void* qkv, const void* out, const void* dout, const float* lse, float* delta, float* dq_part, void* dqkv,
-                         int NB, int L, int H, int hd, int dt, void* stream) {
     STAR_CHECK(qkv && out && dout && lse && delta && dqkv, "star_attn_bwd: null pointer");
     if (int rc = attn_check("star_attn_bwd", NB, L, H, hd, dt)) return rc;
     STAR_CHECK(dt != STAR_BF16X3, "star_attn_bwd: STAR_BF16X3 is a forward-only storage type");
@@ -1450,18 +1070,8 @@ static int attn_bwd_impl(const void* qkv, const void* out, const void* dout, con
     const int64_t items = (int64_t)NB * L * H;
     int rc = 0;
     if (dt == STAR_BF16) {
-        const bool fused = dq_part != nullptr && hd <= 32;
-        if (fused) {   // the single-sweep kernel reads both row-constant tables: one pass in front of it writes them
-            const dim3 dgrid(NB * cdiv(L, 64));
-            const size_t dlds = (size_t)H * 65 * sizeof(float);
-            if (hd == 16) hipLaunchKernelGGL(attn_delta_bf16_kernel<16>, dgrid, dim3(256), dlds, s, (const bf16_t*)out, (const bf16_t*)dout, lse, delta, NB, L, H, 1.0f / c);
-            else hipLaunchKernelGGL(attn_delta_bf16_kernel<32>, dgrid, dim3(256), dlds, s, (const bf16_t*)out, (const bf16_t*)dout, lse, delta, NB, L, H, 1.0f / c);
-            STAR_LAUNCH_CHECK("star_attn_bwd(delta)");
-            rc = hd == 16 ? bwd_fused_bf16<16>(qkv, dout, delta, dq_part, dqkv, NB, L, H, c, scale, s)
-                          : bwd_fused_bf16<32>(qkv, dout, delta, dq_part, dqkv, NB, L, H, c, scale, s);
-        }
         // two kernels: the dQ kernel computes the row dots in its prologue and leaves the tables for the dK/dV kernel behind it
-        else if (hd == 16) rc = bwd_bf16<16>(qkv, out, dout, lse, delta, dqkv, NB, L, H, c, scale, s);
+        if (hd == 16) rc = bwd_bf16<16>(qkv, out, dout, lse, delta, dqkv, NB, L, H, c, scale, s);
         else if (hd == 32) rc = bwd_bf16<32>(qkv, out, dout, lse, delta, dqkv, NB, L, H, c, scale, s);
         else rc = bwd_bf16<64>(qkv, out, dout, lse, delta, dqkv, NB, L, H, c, scale, s);
     } else {

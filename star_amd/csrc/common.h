@@ -125,3 +125,14 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
 }
 
 static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) belongs to the CURRENT device: a "done" flag has to be kept per device ordinal.
+// Returns true the first time it sees the current device with this mask (a race between two threads sets the attribute twice: harmless).
+static inline bool star_once_per_device(unsigned long long& mask) {
+    int d = 0;
+    (void)hipGetDevice(&d);
+    const unsigned long long bit = 1ull << (d & 63);
+    if (mask & bit) return false;
+    mask |= bit;
+    return true;
+}

@@ -703,12 +703,10 @@ static void launch_nt_fast_cg(const StarGemm* g, hipStream_t s) {
     constexpr int BM = WM * RB * 16, BN = WN * 64;
     const int tiles = cdiv(g->M, BM) * cdiv(g->N, BN);
     const size_t lds = (size_t)NST * (BM + BN) * 64;   // the ring only: the epilogue does not stage through LDS
-    static bool attr_done = false;
-    if (!attr_done && lds > 48 * 1024) {
+    static unsigned long long attr_done = 0;       // per device ordinal
+    if (lds > 48 * 1024 && star_once_per_device(attr_done))
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_fast_kernel<NST, EPI, WM, WN, RB, CG>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)lds);
-        attr_done = true;
-    }
     // The kernel can walk several tiles per block (grid < tiles), prefilling the next tile's ring under the epilogue.
     // Measured on MI355X this is no faster than one tile per block, so every tile gets its own block and the hardware
     // dispatcher balances the tail.
@@ -729,8 +727,8 @@ static void launch_nt_fast_geo(const StarGemm* g, hipStream_t s) {
 //   24.9 -> 18.1 us, the fc1 input gradient 19.9 -> 15.5; at M = 10 240 the same shapes lose 5-15 %).  STAR_AMD_GEMM_GEO=0..3 forces one geometry.
 template <int EPI>
 static int nt_geometry(const StarGemm* g) {
-    static const char* env = getenv("STAR_AMD_GEMM_GEO");
-    if (env && env[0] >= '0' && env[0] <= '2') return env[0] - '0';
+    const char* env = getenv("STAR_AMD_GEMM_GEO");      // read per call: a test walks the geometries
+    if (env && env[0] >= '0' && env[0] <= '3') return env[0] - '0';
     if ((long long)cdiv(g->M, 128) * cdiv(g->N, 128) * 2 <= star_num_cus()) return 3;   // few tiles: halve them (one-scene inference)
     if (EPI == EPI_LINEAR && (long long)cdiv(g->M, 256) * cdiv(g->N, 128) >= star_num_cus()) return 1;
     if (EPI == EPI_GELU_GRAD && g->N >= 1536 && (long long)cdiv(g->M, 256) * cdiv(g->N, 256) >= 2 * star_num_cus()) return 2;
@@ -929,11 +927,9 @@ static bool launch_nt_wreg(const StarGemm* g, hipStream_t s) {
     const int cus = star_num_cus();
     if (l > cus) return false;
     const int grid = cus / l * l;
-    static bool attr = false;
-    if (!attr) {
+    static unsigned long long attr = 0;            // per device ordinal
+    if (star_once_per_device(attr))
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_wreg_kernel<12, 3, RB, EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        attr = true;
-    }
     hipLaunchKernelGGL((gemm_nt_wreg_kernel<12, 3, RB, EPI>), dim3(grid), dim3(256), (size_t)LDS, s, *g, g->M / BM);
     return true;
 }

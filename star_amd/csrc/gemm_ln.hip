@@ -240,12 +240,11 @@ static int launch_res_ln(const void* A, const void* W, const float* bias, const 
                          const float* beta, float eps, void* h, float* mean, float* rstd, int M, int K, hipStream_t s) {
     constexpr int BM = WM * RB * 16, N = WN * 64;
     const size_t lds = (size_t)NST * (BM + N) * 64 + (size_t)2 * BM * WN * sizeof(float);
-    static bool attr_done = false;
-    if (!attr_done && lds > 48 * 1024) {
+    static unsigned long long attr_done = 0;       // per device ordinal: the attribute belongs to the current device
+    if (lds > 48 * 1024 && star_once_per_device(attr_done)) {
         const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_res_ln_kernel<NST, WM, WN, RB>),
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return star_set_error(-2, "star_gemm_res_ln: LDS attribute: %s", hipGetErrorString(e));
-        attr_done = true;
     }
     hipLaunchKernelGGL((gemm_res_ln_kernel<NST, WM, WN, RB>), dim3(cdiv(M, BM)), dim3(WM * WN * 64), lds, s, (const bf16_t*)A,
                        (const bf16_t*)W, bias, res, xout, gamma, beta, (bf16_t*)h, mean, rstd, M, K, eps);

@@ -3,6 +3,8 @@
 // (star/models/mae_base.py:279-282,308-312).  HBM-bound: one wave per row, the row lives in registers,
 // 16-byte loads, wavefront reductions; the normalised row leaves in the activation type so that the
 // following MFMA GEMM reads half the bytes.
+#include <atomic>
+
 #include "common.h"
 
 #define LN_THREADS 256
@@ -273,8 +275,11 @@ __global__ __launch_bounds__(1024) void ln_fold_batch_kernel(const StarLnFoldJob
         float a = 0.f;
 #pragma unroll
         for (int r = 0; r < 64; ++r) a += s[r][cl];
-        if (e < D) j.dgamma[e] = a;
-        else j.dbeta[e - D] = a;
+        if (e < D) {
+            if (j.dgamma) j.dgamma[e] = a;
+        } else if (j.dbeta) {
+            j.dbeta[e - D] = a;
+        }
     }
 }
 
@@ -305,7 +310,7 @@ extern "C" int star_layernorm_bwd(const void* dy, const float* x, const float* g
 #define LN_STATIC_MAX_D 1024
 #define LN_STATIC_MAX_DEV 64
 static __device__ __align__(256) float scratch[(size_t)LN_BWD_BLOCKS * 2 * LN_STATIC_MAX_D];   // 6 MiB
-static float* volatile g_scratch_ptr[LN_STATIC_MAX_DEV];
+static std::atomic<float*> g_scratch_ptr[LN_STATIC_MAX_DEV];      // racing first calls store the same address
 
 extern "C" int star_layernorm_bwd_static(const void* dy, const float* x, const float* gamma, const float* mean,
                                          const float* rstd, const float* g_in, float* g_out, void* g_out_lp,
@@ -315,12 +320,12 @@ extern "C" int star_layernorm_bwd_static(const void* dy, const float* x, const f
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return star_set_error(-2, "star_layernorm_bwd_static: hipGetDevice: %s", hipGetErrorString(e));
     STAR_CHECK(dev >= 0 && dev < LN_STATIC_MAX_DEV, "star_layernorm_bwd_static: device %d out of range", dev);
-    float* ptr = g_scratch_ptr[dev];
+    float* ptr = g_scratch_ptr[dev].load(std::memory_order_acquire);
     if (ptr == nullptr) {   // once per device, with that device current: every GPU holds its own copy of the array
         e = hipGetSymbolAddress((void**)&ptr, HIP_SYMBOL(scratch));
         if (e != hipSuccess || ptr == nullptr)
             return star_set_error(-2, "star_layernorm_bwd_static: hipGetSymbolAddress: %s", hipGetErrorString(e));
-        g_scratch_ptr[dev] = ptr;
+        g_scratch_ptr[dev].store(ptr, std::memory_order_release);
     }
     return ln_bwd_launch(dy, x, gamma, mean, rstd, g_in, g_out, g_out_lp, dgamma, dbeta, ptr, M, D, dt, stream);
 }

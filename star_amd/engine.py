@@ -189,7 +189,8 @@ def _block_fwd(x, P, W, pre, heads, nb, l, dt, eps, save, train, ln1=None, nxt=N
     ln = (h, mean, rstd) of that LayerNorm (from the fc2 kernel where star_gemm_res_ln covers the shape), else x_out alone."""
     d = x.shape[1]
     hd = d // heads
-    fuse_ln = _GEMM_LN and dt == BF16 and ops.gemm_res_ln_prefers(x.shape[0], d, d, dt)
+    fuse_ln = _GEMM_LN and dt == BF16 and ops.gemm_res_ln_prefers(x.shape[0], d, d, dt, x, P[pre + "attn.proj.bias"], P[pre + "norm2.weight"],
+                                                                  P[pre + "norm2.bias"])
     h1, mean1, rstd1 = ln1 if ln1 is not None else ops.layernorm_fwd(x, P[pre + "norm1.weight"], P[pre + "norm1.bias"], eps, dt, want_stats=train)
     qkv, _, _ = ops.gemm(h1, _lin(P, W, pre + "attn.qkv", dt), bias=P[pre + "attn.qkv.bias"], dt=dt)
     a, lse = ops.attn_fwd(qkv, nb, l, heads, hd, dt=dt)
@@ -203,17 +204,15 @@ def _block_fwd(x, P, W, pre, heads, nb, l, dt, eps, save, train, ln1=None, nxt=N
     # u is not the pre-activation but gelu'(pre-activation): all the backward needs of it (flag PRE_IS_GRAD)
     w1, w2 = _lin(P, W, pre + "mlp.fc1", dt), _lin(P, W, pre + "mlp.fc2", dt)
     ln = None
-    if _MLP_FUSED and dt == BF16 and ops.mlp_supported(d, w1.shape[0], dt):
-        x_out, v, u = ops.mlp_fwd(h2, w1, P[pre + "mlp.fc1.bias"], w2, P[pre + "mlp.fc2.bias"], x_mid, train, out=None if train else x_mid)
+    v, _, u = ops.gemm(h2, w1, bias=P[pre + "mlp.fc1.bias"], act=ACT_GELU, want_pre=train, flags=GEMM_PRE_IS_GRAD, dt=dt)
+    if nxt is not None and _GEMM_LN and dt == BF16 and ops.gemm_res_ln_prefers(x.shape[0], d, w1.shape[0], dt, P[pre + "mlp.fc2.bias"],
+                                                                               P[nxt + ".weight"], P[nxt + ".bias"]):
+        x_out, hn, mean_n, rstd_n = ops.gemm_res_ln(v, w2, P[pre + "mlp.fc2.bias"], x_mid, P[nxt + ".weight"], P[nxt + ".bias"], eps,
+                                                    want_stats=train, out=None if train else x_mid)
+        ln = (hn, mean_n, rstd_n)
     else:
-        v, _, u = ops.gemm(h2, w1, bias=P[pre + "mlp.fc1.bias"], act=ACT_GELU, want_pre=train, flags=GEMM_PRE_IS_GRAD, dt=dt)
-        if nxt is not None and _GEMM_LN and dt == BF16 and ops.gemm_res_ln_prefers(x.shape[0], d, w1.shape[0], dt):
-            x_out, hn, mean_n, rstd_n = ops.gemm_res_ln(v, w2, P[pre + "mlp.fc2.bias"], x_mid, P[nxt + ".weight"], P[nxt + ".bias"], eps,
-                                                        want_stats=train, out=None if train else x_mid)
-            ln = (hn, mean_n, rstd_n)
-        else:
-            _, x_out, _ = ops.gemm(v, w2, bias=P[pre + "mlp.fc2.bias"], res=x_mid, want_lp=False, want_f32=True,
-                                   out_f32=None if train else x_mid, dt=dt)
+        _, x_out, _ = ops.gemm(v, w2, bias=P[pre + "mlp.fc2.bias"], res=x_mid, want_lp=False, want_f32=True,
+                               out_f32=None if train else x_mid, dt=dt)
     if train:
         save.append(dict(pre=pre, x=x, mean1=mean1, rstd1=rstd1, h1=h1, qkv=qkv, a=a, lse=lse, x_mid=x_mid, mean2=mean2,
                          rstd2=rstd2, h2=h2, u=u, v=v, heads=heads, nb=nb, l=l))
@@ -311,7 +310,6 @@ class _SideStream:
 
 
 _GEMM_LN = os.environ.get("STAR_AMD_GEMM_LN", "1") == "1"           # proj / fc2 + residual + the LayerNorm behind them in one launch (star_gemm_res_ln)
-_MLP_FUSED = os.environ.get("STAR_AMD_MLP_FUSED", "0") == "1"       # the block MLP forward as one kernel (star_mlp_fwd): measured slower, opt-in
 _SKIP_WGRAD = os.environ.get("STAR_AMD_SKIP_WGRAD", "0") == "1"   # measurement only (wrong gradients): the backward chain without its weight-gradient GEMMs
 
 

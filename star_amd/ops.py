@@ -96,7 +96,16 @@ def warp_fuse(pred_u8, theta, num_agent, batch, ego=None, binary=False):
     ws = None
     if binary and c <= 16:
         ws = torch.empty(L.lib().star_warp_fuse_ws(batch, a, h, w) // 8 + 1, dtype=torch.int64, device=pred_u8.device)
-    with _timed("warp_fuse", 0.0, float(ab) * (a + 1) * c * h * w * 4):   # (A+1) x 3.41 MB per ego frame
+    # bytes the launch has to move in ITS operand formats.  Bit-packed path (what training and inference run): the uint8 decisions
+    # once (pack), one 2-byte word per pixel written by the pack and gathered per (pixel, agent) by the fusion, the float32 map
+    # written once, the float32 ego map read once in inference.  (SURVEY 8d's (A + 1) x 3.41 MB per ego frame prices the reference's
+    # float32 gathers: 4-5x these bytes.)  Byte-gather path: A uint8 gathers per voxel instead.
+    hw = float(h) * w
+    if ws is not None:
+        nbytes = ab * (c * hw * 1 + hw * 2 + a * hw * 2 + c * hw * 4 + (c * hw * 4 if ego is not None else 0))
+    else:
+        nbytes = ab * (a * c * hw * 1 + c * hw * 4 + (c * hw * 4 if ego is not None else 0))
+    with _timed("warp_fuse", 0.0, float(nbytes)):
         L.check(L.lib().star_warp_fuse(p(pred_u8), p(ego), es[0], es[1], es[2], es[3], p(theta), p(num_agent),
                                        int(num_agent.dtype == torch.int64), p(out), p(ws), batch, a, c, h, w, L.stream()))
     return out
@@ -286,8 +295,12 @@ def gemm_res_ln_supported(n, k, dt):
     return bool(L.lib().star_gemm_res_ln_supported(n, k, dt))
 
 
-def gemm_res_ln_prefers(m, n, k, dt):
-    """a kernel exists AND is expected to beat star_gemm + star_layernorm_fwd at this M (whole-row tiles: M sets the tile count)"""
+def gemm_res_ln_prefers(m, n, k, dt, *operands):
+    """a kernel exists AND is expected to beat star_gemm + star_layernorm_fwd at this M (whole-row tiles: M sets the tile count) AND
+    every operand given (bias / gamma / beta / residual views) is 16-byte aligned, as star_gemm_res_ln requires -- parameters that
+    are views at odd offsets into other storage take the two-launch path instead of raising"""
+    if any(t is not None and t.data_ptr() % 16 != 0 for t in operands):
+        return False
     return bool(L.lib().star_gemm_res_ln_prefers(m, n, k, dt))
 
 
@@ -313,29 +326,6 @@ def gemm_res_ln(a, w, bias, res, gamma, beta, eps, want_stats=True, out=None):
     return out, h, mean, rstd
 
 
-def mlp_supported(d, hid, dt):
-    return bool(L.lib().star_mlp_fwd_supported(d, hid, dt))
-
-
-def mlp_fwd(h, w1, b1, w2, b2, xres, train, out=None):
-    """x_out = xres + fc2(gelu(fc1(h))) in one kernel (star_mlp_fwd).  h [M, D], w1 [HID, D], w2 [D, HID] bf16; xres float32 [M, D].
-    Returns (x_out float32, v, g): v = gelu(u), g = gelu'(u) ([M, HID] bf16) when `train`, else None.  `out` may be xres."""
-    _cuda(h, w1, w2, xres)
-    m, d = h.shape
-    hid = w1.shape[0]
-    dt = L.dt_of(h)
-    assert h.is_contiguous() and w1.is_contiguous() and w2.is_contiguous() and xres.is_contiguous()
-    assert w1.shape == (hid, d) and w2.shape == (d, hid) and xres.shape == (m, d) and xres.dtype == torch.float32
-    assert w1.dtype == h.dtype and w2.dtype == h.dtype and b1.dtype == torch.float32 and b2.dtype == torch.float32
-    if out is None:
-        out = torch.empty_like(xres)
-    v = torch.empty(m, hid, dtype=h.dtype, device=h.device) if train else None
-    g = torch.empty(m, hid, dtype=h.dtype, device=h.device) if train else None
-    with _timed("mlp_fwd", 4.0 * m * d * hid, float(m * d * (2 + 4 + 4) + (2 * m * hid * 2 if train else 0))):
-        L.check(L.lib().star_mlp_fwd(p(h), p(w1), p(b1), p(w2), p(b2), p(xres), p(out), p(v), p(g), m, d, hid, dt, L.stream()))
-    return out, v, g
-
-
 # ---------------------------------------------------------------------------------------------------
 def attn_fwd(qkv, nb, l, h, hd, dt=None):
     """qkv [NB*L, 3*H*hd] -> (out [NB*L, H*hd], lse float32 [NB, H, L]).  dt = BF16X3: rows of bf16 hi/lo pairs, twice as wide."""
@@ -351,24 +341,12 @@ def attn_fwd(qkv, nb, l, h, hd, dt=None):
     return out, lse
 
 
-_ATTN_FUSED = os.environ.get("STAR_AMD_ATTN_FUSED", "0") == "1"
-
-
-def attn_bwd(qkv, out, dout, lse, nb, l, h, hd, fused=None):
-    """dqkv [NB*L, 3*H*hd].  fused=True: star_attn_bwd_ws (bf16, hd <= 32: one sweep over the scores for dQ, dK, dV);
-    fused=False: star_attn_bwd (a dQ kernel and a dK/dV kernel, each recomputing the scores).  Default: the two-kernel
-    path (faster inside the training step as measured), STAR_AMD_ATTN_FUSED=1 switches."""
-    if fused is None:
-        fused = _ATTN_FUSED
+def attn_bwd(qkv, out, dout, lse, nb, l, h, hd):
+    """dqkv [NB*L, 3*H*hd] (star_attn_bwd: a dQ kernel and a dK/dV kernel, each recomputing the scores from the stored row
+    log-sum-exp; no atomics, bitwise reproducible)."""
     dt = L.dt_of(qkv)
     assert qkv.is_contiguous() and out.is_contiguous() and dout.is_contiguous() and dout.dtype == qkv.dtype
     dqkv = torch.empty_like(qkv)
-    if fused:
-        nbytes = L.lib().star_attn_bwd_ws_bytes(nb, l, h, hd, dt)
-        ws = torch.empty(nbytes // 4, dtype=torch.float32, device=qkv.device)   # delta | scaled lse | fp32 dQ partial (L > 512)
-        with _timed("attn_bwd", 10.0 * nb * h * l * l * hd):
-            L.check(L.lib().star_attn_bwd_ws(p(qkv), p(out), p(dout), p(lse), p(ws), nbytes, p(dqkv), nb, l, h, hd, dt, L.stream()))
-        return dqkv
     delta = torch.empty(2, nb, h, l, dtype=torch.float32, device=qkv.device)   # workspace: delta | scaled lse
     with _timed("attn_bwd", 10.0 * nb * h * l * l * hd):
         L.check(L.lib().star_attn_bwd(p(qkv), p(out), p(dout), p(lse), p(delta), p(dqkv), nb, l, h, hd, dt, L.stream()))
@@ -387,8 +365,9 @@ def patchify(img1, img_next, t, patch, dt, channels_last_order=False):
     if t > 1:
         assert img_next.dtype == torch.float32 and tuple(img_next.shape) == (ba, t - 1, c, h, w)
         sn = L.strides(img_next)
-    L.check(L.lib().star_patchify(p(img1), L.strides(img1), p(img_next) if t > 1 else None, sn, p(out), ba, t, c, h, w,
-                                  patch, dt | (256 if channels_last_order else 0), L.stream()))
+    with _timed("patchify", 0.0, float(ba) * t * c * h * w * (4 + out.element_size())):      # float32 voxels in, the patch matrix out
+        L.check(L.lib().star_patchify(p(img1), L.strides(img1), p(img_next) if t > 1 else None, sn, p(out), ba, t, c, h, w,
+                                      patch, dt | (256 if channels_last_order else 0), L.stream()))
     return out
 
 
@@ -406,7 +385,11 @@ def ce_argmax(logits, target, patch, dt, want_pred=False, want_dlogits=True, wan
     nb = L.lib().star_ce_nblocks(ba, c, h, w)
     part = torch.empty(nb, dtype=torch.float32, device=dev) if want_loss else None
     loss = torch.empty(1, dtype=torch.float32, device=dev) if want_loss else None
-    with _timed("ce_argmax", 0.0, float(ba) * c * h * w * 16):            # 13.6 MB per frame
+    # per voxel: two float32 logits + the float32 target read; the int64 decision (the API's ind_result) + its uint8 copy (the fusion's
+    # input) written; + the two logit gradients in training, + the [BA,2,C,H,W] float32 logits tensor when a test asks for it.
+    # (SURVEY 8d counts 16 B / voxel, a 4-byte decision word; PMC on MI355X: 409 MB fetched + 443 MB written per 40 frames = 25 B / voxel.)
+    per_voxel = 8 + 4 + 8 + 1 + (2 * (2 if dt == BF16 else 4) if want_dlogits else 0) + (8 if want_pred else 0)
+    with _timed("ce_argmax", 0.0, float(ba) * c * h * w * per_voxel):
         L.check(L.lib().star_ce_argmax(p(logits), p(target), L.strides(target), p(ind64), p(ind8), p(pred), p(dlog), p(part),
                                        ba, c, h, w, patch, dt, L.stream()))
     if want_loss:

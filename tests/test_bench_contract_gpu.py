@@ -34,7 +34,11 @@ def test_bench_line_train():
     assert abs(s["gflop_per_frame"] - 131.77) < 0.1 and abs(s["frac_of_mfma_peak"] - j["value"] * 131.77e9 / 2.5e15) < 2e-3
     fam = {f["kernel"] for f in j["families"]}
     assert {"gemm_nt", "gemm_wgrad", "attn_bwd"} <= fam
+    for f in j["families"] + j["bandwidth_path"]:
+        assert 0 < f["frac"] <= 1.0, f                      # a fraction of a peak: never above it
+    assert {"ce_argmax", "warp_fuse"} <= {f["kernel"] for f in j["bandwidth_path"]}
     c = j["cpu_baseline"]
+    assert c["machine_physical_cores"] is None or c["machine_physical_cores"] >= 1
     assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and c["sample"] and c["cpu_model"]
     assert c["value"] == c["train_frames_per_s"] and c["infer_frames_per_s"] > c["train_frames_per_s"]
 
@@ -42,3 +46,10 @@ def test_bench_line_train():
 def test_bench_line_infer_has_no_cpu_leg():
     j = _run("--mode", "infer", "--no-cpu-baseline")
     assert "infer" in j["metric"] and "cpu_baseline" not in j and j["roofline"]["frac"] > 0
+    for f in j["families"] + j["bandwidth_path"]:
+        assert 0 < f["frac"] <= 1.0, f
+
+
+def test_bench_line_infer_bf16x3():
+    j = _run("--mode", "infer", "--no-cpu-baseline", "--dtype", "bf16x3")
+    assert j["dtype"] == "bf16x3" and j["value"] > 100 and abs(j["step_roofline"]["peak_tflops"] - 2500.0 / 3) < 1.0

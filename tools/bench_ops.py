@@ -113,28 +113,6 @@ def gemm_ln_cases():
     return rows
 
 
-def mlp_cases():
-    """block MLP forward: the one-kernel path against the two GEMM launches (training: with the gelu / gelu' stores)."""
-    rows = []
-    g = torch.Generator().manual_seed(0)
-    for name, D, HID in [("enc mlp", 384, 1536), ("dec mlp", 256, 1024)]:
-        h = torch.randn(M, D, generator=g).to(dev).bfloat16()
-        w1 = (torch.randn(HID, D, generator=g) * D ** -0.5).to(dev).bfloat16()
-        w2 = (torch.randn(D, HID, generator=g) * HID ** -0.5).to(dev).bfloat16()
-        b1, b2 = torch.zeros(HID, device=dev), torch.zeros(D, device=dev)
-        xres = torch.randn(M, D, generator=g).to(dev)
-        for train in (True, False):
-            def two():
-                v, _, u = ops.gemm(h, w1, bias=b1, act=ACT_GELU, want_pre=train, flags=GEMM_PRE_IS_GRAD)
-                ops.gemm(v, w2, bias=b2, res=xres, want_lp=False, want_f32=True)
-            us2 = timeit(two)
-            us1 = timeit(lambda: ops.mlp_fwd(h, w1, b1, w2, b2, xres, train))
-            tag = " train" if train else " infer"
-            rows.append((name + tag + " 2 gemms", D, HID, us2, 4.0 * M * D * HID / us2 / 1e6, 0.0))
-            rows.append((name + tag + " fused", D, HID, us1, 4.0 * M * D * HID / us1 / 1e6, 0.0))
-    return rows
-
-
 def attn_cases():
     rows = []
     g = torch.Generator().manual_seed(0)
@@ -208,8 +186,8 @@ def vq_cases():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["gemm", "wgrad", "mlp", "attn", "ln", "voxel", "vq"]
+    which = sys.argv[1:] or ["gemm", "wgrad", "wgroup", "attn", "ln", "voxel", "vq"]
     for w in which:
-        rows = dict(gemm=gemm_cases, gemm_ln=gemm_ln_cases, wgrad=wgrad_cases, wgroup=wgroup_cases, mlp=mlp_cases, attn=attn_cases, ln=ln_cases, voxel=voxel_cases, vq=vq_cases)[w]()
+        rows = dict(gemm=gemm_cases, gemm_ln=gemm_ln_cases, wgrad=wgrad_cases, wgroup=wgroup_cases, attn=attn_cases, ln=ln_cases, voxel=voxel_cases, vq=vq_cases)[w]()
         for name, a, b, us, tf, gbs in rows:
             print("%-26s %5d %5d  %8.1f us  %7.1f TFLOP/s  %7.1f GB/s(or Gexp/s)" % (name, a, b, us, tf, gbs))

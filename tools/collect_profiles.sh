@@ -16,7 +16,7 @@ echo "pmc traffic done"
 bash tools/pmc_mfma.sh gpurun_out/$tag/pmc_mfma.json > $out/pmc_mfma_summary.txt 2>&1 || { tail -5 $out/pmc_mfma_summary.txt; exit 1; }
 echo "pmc mfma done"
 : > $out/bench_other_configs.jsonl
-for flags in "--dtype fp32" "--mode infer --batch 16" "--mode infer --batch 16 --dtype fp32" "--mode infer --batch 1" "--mode infer --batch 1 --dtype fp32" \
+for flags in "--dtype fp32" "--mode infer --batch 16" "--mode infer --batch 16 --dtype bf16x3" "--mode infer --batch 16 --dtype fp32" "--mode infer --batch 1" "--mode infer --batch 1 --dtype bf16x3" "--mode infer --batch 1 --dtype fp32" \
              "--time_stamp 3" "--time_stamp 3 --mask random --mask_ratio 0.75" "--time_stamp 3 --mask random --mask_ratio 0.9" \
              "--time_stamp 2 --mask random --mask_ratio 0.9" "--com vqstar"; do
   timeout -k 10 200 python bench.py --no-cpu-baseline --steps 20 --warmup 5 $flags >> $out/bench_other_configs.jsonl 2>> $out/bench_other.err || exit 1

@@ -16,7 +16,7 @@ workload = None      # the bench line of the profiled run names the workload the
 for line in open("%s/p.log" % d):
     if line.startswith("{") and '"workload"' in line:
         workload = json.loads(line)["config"]["workload"]
-fam = [("gemm_nt", ("void gemm_nt_",)), ("gemm_wgrad", ("void gemm_tn_",)), ("mlp_fwd", ("void mlp_fwd_",)), ("gemm_res_ln", ("void gemm_res_ln_",)), ("attn_fwd", ("void attn_fwd_",)),
+fam = [("gemm_nt", ("void gemm_nt_",)), ("gemm_wgrad", ("void gemm_tn_",)), ("gemm_res_ln", ("void gemm_res_ln_",)), ("attn_fwd", ("void attn_fwd_",)),
        ("attn_bwd", ("void attn_bwd_",)), ("vq_assign", ("void vq_assign_",))]
 agg = collections.defaultdict(lambda: collections.defaultdict(float))
 n = collections.Counter()
