@@ -89,7 +89,7 @@ def _pmc_mfma_util(family, workload):
     return round(v["mfma_util_busy_cycles"], 4) if v and v.get("mfma_util_busy_cycles") is not None else None
 
 
-def flops_per_frame(c, mask, mask_ratio, train):
+def flops_per_frame(c, mask, mask_ratio, train, joint=False):
     """algorithmic FLOPs (2 x MACs) per output frame of the configured model; train = 3 x forward."""
     import math
     L, D, Dd, V, T = c.L, c.dim, c.ddim, c.V, c.T
@@ -99,6 +99,20 @@ def flops_per_frame(c, mask, mask_ratio, train):
         return 2 * l * 12 * dm * dm + 4 * l * l * dm
 
     l_enc = keep if c.encode_partial else L
+    if joint:
+        # encoder on every token, decoder blocks, then two conv heads: stage s = bilinear x2 + 3x3 conv at (grid 2^s)^2 pixels
+        # (ConvPred 512 -> 256 -> 128 -> C at patch 8: mae_base.py:16-54)
+        enc = 2 * L * V * D + c.depth * block(D, L) + 2 * keep * D * c.inter
+        dec = T * (2 * keep * c.inter * D + 2 * keep * D * Dd) + c.ddepth * block(Dd, L)
+        px, cin = c.grid * c.grid, Dd
+        stages = int(math.log2(c.patch))
+        head = 0
+        for st in range(stages):
+            px *= 4
+            cout = c.chans if st == stages - 1 else cin // 2
+            head += 2 * px * 9 * cin * cout
+            cin = cout
+        return (T * enc + dec + 2 * head) * (3 if train else 1)
     enc = 2 * l_enc * V * D + c.depth * block(D, l_enc) + 2 * keep * D * c.inter
     dec = T * (2 * keep * c.inter * D + 2 * keep * D * Dd) + c.ddepth * block(Dd, L) + 2 * L * Dd * 2 * V
     return (T * enc + dec) * (3 if train else 1)
@@ -233,6 +247,12 @@ def main():
         model = VQSTAR.vqstar(time_stamp=args.time_stamp, mask_method=args.mask, num_vq_embeddings=8192, vq_embedding_dim=32)
         model = model.to(dev).set_compute_dtype(args.dtype)
         opt = FlatAdamW(model, lr=1e-3, betas=(0.9, 0.999), weight_decay=0.0, grouping="flat")
+    elif args.model.startswith("amortized_joint"):
+        # the joint (latent-level fusion) variant, SURVEY 8(f) rank 1: torch AdamW over timm's decay groups, as train_completion.py builds it
+        from star_amd.optim import add_weight_decay
+        args.com = "joint_mae"
+        model = getattr(mm, args.model)(time_stamp=args.time_stamp, mask_method=args.mask).to(dev).set_compute_dtype(args.dtype)
+        opt = torch.optim.AdamW(add_weight_decay(model, 0.05), lr=1e-3, betas=(0.9, 0.95))
     else:
         model = getattr(mm, args.model)(time_stamp=args.time_stamp, mask_method=args.mask).to(dev).set_compute_dtype(args.dtype)
         opt = FlatAdamW(model, lr=1e-3, betas=(0.9, 0.95), weight_decay=0.05)
@@ -255,6 +275,9 @@ def main():
                 loss, result, _, _ = cm.step_vqstar_completion(data, args.batch, args.mask_ratio, trainable=True)
             else:
                 loss, result, _ = cm.step_mae_completion(data, args.batch, args.mask_ratio, trainable=True)
+        elif args.com == "joint_mae":       # the reference's joint model has no inference(): its forward without the autograd edge
+            with torch.no_grad():
+                loss = model(*cm._unpack(data), args.batch, mask_ratio=args.mask_ratio)[0]
         elif args.com == "vqstar":
             loss = cm.infer_vqstar_completion(data, args.batch, args.mask_ratio)[0]
         else:
@@ -334,7 +357,7 @@ def main():
                 print("  %-14s %4d launches %8.3f ms (%4.1f%%) %8.1f TFLOP/s %8.1f GB/s" % (
                     k, v["launches"], v["ms"], 100 * v["ms"] / tot, v["flops"] / (v["ms"] * 1e-3 + 1e-12) / 1e12,
                     v["bytes"] / (v["ms"] * 1e-3 + 1e-12) / 1e9), file=sys.stderr)
-        fpf = flops_per_frame(model._cfg(), args.mask, args.mask_ratio, args.mode == "train")
+        fpf = flops_per_frame(model._cfg(), args.mask, args.mask_ratio, args.mode == "train", joint=args.com == "joint_mae")
         out = {
             "metric": "BEV frames/sec (5-agent scenes, %s)" % ("train" if args.mode == "train" else "infer"),
             "value": round(value, 2), "unit": "BEV frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

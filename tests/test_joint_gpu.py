@@ -4,8 +4,8 @@ captured from the reference (fp32 mode: the bar for this row), and the registere
 
 The fused latent is a THRESHOLD of summed float features (fusion("sum")), so a feature within rounding distance of 0.5 may land
 on the other side: elements are compared where the reference's pre-threshold sum is not within 1e-3 of 0.5, and everything
-downstream only when no element flipped (true for every fixture in fp32 mode).  bf16 mode runs (smoke) but is not held to a
-bound: bf16 rounding of the features moves ~1 % of the thresholded elements, each by a full unit."""
+downstream only when no element flipped (true for every fixture in fp32 mode).  bf16 mode is held to MEASURED bounds
+(test_joint_fixture_bf16_bounded): 0.03 ... 0.23 % of the thresholded elements flip, each by a full unit."""
 from functools import partial
 
 import numpy as np
@@ -81,13 +81,43 @@ def test_joint_fixture_fp32(name):
             assert torch.equal(m.state_dict()[k].cpu().to(v.dtype), c.sd[k].to(v.dtype)), k
 
 
-def test_joint_bf16_mode_runs():
-    c = JointCase("joint_T2_rand_train")
+@pytest.mark.parametrize("name", JOINT_CASES)
+def test_joint_fixture_bf16_bounded(name):
+    """bf16 mode on the reference-captured fixtures.  The pre-threshold feature path ends in float32 (decoder_embed -> warp -> sum), but
+    the encoder in front of it stores bf16 operands, so a summed feature within ~1e-2 of 0.5 can land on the other side of
+    fusion("sum")'s threshold and enter the decoder as a full unit.  Measured on MI355X (tools/measure_joint_bf16.py, round 3; tiny
+    random-init models, BatchNorm in training mode): features off by 0.5 % rms (max 4.4e-2), 0.03 ... 0.23 % of the thresholded latent
+    flipped, logits off by 9 % of their rms in training mode / 1.3 % in eval mode, loss within 6e-4, decisions differ on 0.6 ... 2.6 %
+    of the voxels (every one at a reference margin < 1.1, the largest |logit| being ~6), gradients 8 ... 10 % of the whole vector.
+    Bounds: about twice those."""
+    c = JointCase(name)
     m = build(c, "bf16")
     loss, result, mask, pred = run(m, c)
-    loss.backward()
-    assert np.isfinite(loss.item()) and abs(loss.item() - c.loss) < 0.2
-    assert all(torch.isfinite(p.grad).all() for p in m.parameters() if p.grad is not None)
+    t = m._taps
+    assert torch.equal(mask.cpu(), torch.from_numpy(c.z["mask"]))                       # index work: exact in any mode
+    ref_feat = c.tap("feat")
+    ferr = t["feat"].cpu().reshape(ref_feat.shape) - ref_feat
+    assert ferr.pow(2).mean().sqrt() < 0.01 * ref_feat.pow(2).mean().sqrt() and ferr.abs().max() < 0.1
+    fused = t["fused"].cpu() - m.decoder_pos_embed[0, 1:].cpu()
+    flips = ((fused - c.tap("fused")).abs() > 0.5).float().mean().item()
+    assert flips < 5e-3, flips
+    pe = pred.cpu() - c.pred
+    assert pe.pow(2).mean().sqrt() < 0.2 * c.pred.pow(2).mean().sqrt(), pe.pow(2).mean().sqrt()
+    assert abs(loss.item() - c.loss) < 2e-3
+    differ = result.cpu().numpy() != c.result
+    margin = (c.pred[:, 1] - c.pred[:, 0]).abs().numpy()
+    assert differ.mean() < 0.05 and (not differ.any() or margin[differ].max() < 2.0)
+    if c.train:
+        loss.backward()
+        params = dict(m.named_parameters())
+        num = den = 0.0
+        for k, g in c.grads().items():
+            if g.numel() == 0 or ".conv" in k and k.endswith(".bias"):      # a conv bias in front of a training-mode BatchNorm: zero gradient
+                continue
+            assert params[k].grad is not None and torch.isfinite(params[k].grad).all(), k
+            num += float((params[k].grad.cpu() - g).pow(2).sum())
+            den += float(g.pow(2).sum())
+        assert (num / den) ** 0.5 < 0.2, (num / den) ** 0.5
 
 
 def test_joint_full_size_factory_against_oracle():
