@@ -1333,6 +1333,8 @@ __global__ __launch_bounds__(NWV * 64) void gemm_tn_fast_kernel(const bf16_t* __
 // so the gradients stay bitwise reproducible without atomics on the data -- and writes dW / db.  The counters return to zero.
 // Work order: split-major, then job, then the tile walk with the SHORTER tile dimension fastest; xcd_remap gives every XCD a
 // contiguous run of it, i.e. a near-rectangular set of tiles of one split, whose dY / X row blocks its L2 fetches once.
+#define TN_GROUP_TABLE 768
+#define TN_GROUP_EMPTY 0xffffffffu
 struct TnGroupArgs {
     const bf16_t* dY[STAR_WGRAD_GROUP_MAX];
     const bf16_t* X[STAR_WGRAD_GROUP_MAX];
@@ -1343,6 +1345,8 @@ struct TnGroupArgs {
     int tile0[STAR_WGRAD_GROUP_MAX + 1];     // first tile (= ticket counter) of job j
     int work0[STAR_WGRAD_GROUP_MAX + 1];     // first work item (= partial-tile slot) of job j: tiles x splits, job-major, split, tile
     int njobs, bias_ld;
+    int table_n;       // > 0: launch index -> work item through `table` (host-planned XCD placement), else the plain job-major order
+    unsigned table[TN_GROUP_TABLE];      // job << 24 | split << 16 | tile, or TN_GROUP_EMPTY (the workgroup exits at once)
     float* slabs;      // [work item][TK x TN] as the accumulators lie
     float* bpart;      // [split][bias_ld]
     int* counters;     // [tiles], zero between launches
@@ -1483,12 +1487,22 @@ __global__ __launch_bounds__(512) void gemm_tn_group_kernel(const TnGroupArgs g)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ int s_last;
     constexpr int WNW = 8 / WKW, TK = 16 * AK * WKW, TN = 16 * BN * WNW;
-    const int work = xcd_remap(blockIdx.x, gridDim.x);
-    int j = 0;
-    while (j + 1 < g.njobs && work >= g.work0[j + 1]) ++j;
-    const int ntile = g.tiles_n[j] * g.tiles_k[j];
-    const int split = (work - g.work0[j]) / ntile;
-    const int t = (work - g.work0[j]) - split * ntile;
+    int j = 0, split, t;
+    if (g.table_n > 0) {
+        // host-planned placement: the tiles of one (job, split) read the same rows of dY and X, so the host deals whole (job, split)
+        // groups to the XCDs (workgroups b and b + 8 share one) -- each operand row block is fetched into ONE L2
+        const unsigned e = g.table[blockIdx.x];
+        if (e == TN_GROUP_EMPTY) return;
+        j = (int)(e >> 24);
+        split = (int)((e >> 16) & 0xff);
+        t = (int)(e & 0xffff);
+    } else {
+        const int work = xcd_remap(blockIdx.x, gridDim.x);
+        while (j + 1 < g.njobs && work >= g.work0[j + 1]) ++j;
+        const int ntile = g.tiles_n[j] * g.tiles_k[j];
+        split = (work - g.work0[j]) / ntile;
+        t = (work - g.work0[j]) - split * ntile;
+    }
     const int tn = g.tiles_n[j], tk = g.tiles_k[j];
     int nt, kt;
     if (tk <= tn) { kt = t % tk; nt = t / tk; } else { nt = t % tn; kt = t / tn; }
@@ -1828,6 +1842,40 @@ static int wgrad_group_plan(const StarWgradJob* jobs, int njobs, int sh, TnGroup
     for (int j = n; j <= STAR_WGRAD_GROUP_MAX; ++j) { a->tile0[j] = tiles; a->work0[j] = work; }
     a->njobs = n; a->bias_ld = bias_ld;
     *ws_floats = n == 0 ? 0 : (int64_t)max_S * bias_ld + (int64_t)work * T.tk * T.tn;
+    // XCD placement: whole (job, split) groups, largest first, each to the XCD with the least tiles so far (LPT); slot i of XCD x is
+    // launch index 8 i + x.  Falls back to the plain order when the padded grid does not fit the table.
+    a->table_n = 0;
+    static const char* tenv = getenv("STAR_AMD_WGRAD_PLACE");       // 0: plain job-major order through xcd_remap (A/B)
+    if (n > 0 && !(tenv && tenv[0] == '0')) {
+        struct Grp { int j, s, sz; };
+        Grp grp[STAR_WGRAD_GROUP_MAX * 32];
+        int ng = 0;
+        for (int j = 0; j < n; ++j)
+            for (int s2 = 0; s2 < a->S[j]; ++s2) grp[ng++] = {j, s2, a->tiles_n[j] * a->tiles_k[j]};
+        for (int i = 1; i < ng; ++i) {          // insertion sort by size, descending (stable: equal sizes keep job / split order)
+            const Grp key = grp[i];
+            int q = i - 1;
+            while (q >= 0 && grp[q].sz < key.sz) { grp[q + 1] = grp[q]; --q; }
+            grp[q + 1] = key;
+        }
+        int load[8] = {0, 0, 0, 0, 0, 0, 0, 0}, owner[STAR_WGRAD_GROUP_MAX * 32];
+        for (int i = 0; i < ng; ++i) {
+            int best = 0;
+            for (int x = 1; x < 8; ++x) if (load[x] < load[best]) best = x;
+            owner[i] = best;
+            load[best] += grp[i].sz;
+        }
+        int longest = 0;
+        for (int x = 0; x < 8; ++x) longest = load[x] > longest ? load[x] : longest;
+        if (longest * 8 <= TN_GROUP_TABLE) {
+            for (int i = 0; i < longest * 8; ++i) a->table[i] = TN_GROUP_EMPTY;
+            int fill[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            for (int i = 0; i < ng; ++i)
+                for (int t = 0; t < grp[i].sz; ++t)
+                    a->table[8 * fill[owner[i]]++ + owner[i]] = ((unsigned)grp[i].j << 24) | ((unsigned)grp[i].s << 16) | (unsigned)t;
+            a->table_n = longest * 8;
+        }
+    }
     return tiles;
 }
 
@@ -1890,7 +1938,7 @@ extern "C" int star_gemm_wgrad_group(const StarWgradJob* jobs, int njobs, float*
         a.bpart = next;
         a.slabs = a.bpart + (size_t)max_S * a.bias_ld;
         next += (n + 3) / 4 * 4;
-        const int work = a.work0[a.njobs];
+        const int work = a.table_n > 0 ? a.table_n : a.work0[a.njobs];
         switch (sh) {
             case 1: if (deep) launch_tn_group<4, 4, 6, 4>(a, work, s); else launch_tn_group<3, 4, 6, 4>(a, work, s); break;
             case 2: if (deep) launch_tn_group<4, 4, 4, 4>(a, work, s); else launch_tn_group<3, 4, 4, 4>(a, work, s); break;
