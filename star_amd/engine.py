@@ -319,9 +319,13 @@ def _wg(grads, G, name, dy, x, x_rows=None, side=None, wait=True, queue=None):
     if _SKIP_WGRAD and G is not None:
         grads[name + ".weight"], grads[name + ".bias"] = G[name + ".weight"], G[name + ".bias"]
         return
-    if queue is not None and ops.wgrad_group_eligible(dy, x, x_rows):
-        grads[name + ".weight"], grads[name + ".bias"] = queue.add(dy, x, None if G is None else G[name + ".weight"],
-                                                                   None if G is None else G[name + ".bias"])
+    if queue is not None and ops.wgrad_group_eligible(dy, x):
+        # a row gather (the compressor reads the kept tokens only) becomes a gathered COPY of x, made on the launching stream right
+        # before the grouped launch: pure data movement (M x K bf16), which keeps the product in the grouped kernel; rows with
+        # x_rows < 0 are padding slots whose dy rows are zero (their outputs are dropped on the way to the decoder), so any row serves
+        xg = x if x_rows is None else (lambda: x.index_select(0, x_rows.clamp(min=0).long()))
+        grads[name + ".weight"], grads[name + ".bias"] = queue.add(dy, xg, None if G is None else G[name + ".weight"],
+                                                                   None if G is None else G[name + ".bias"], keep=(x, x_rows))
         return
 
     def run():
@@ -351,13 +355,16 @@ class _WgQueue:
     def __init__(self, side):
         self.side, self.jobs, self.post = side, [], []
 
-    def add(self, dy, x, dw, db, post=None):
+    def add(self, dy, x, dw, db, post=None, keep=()):
+        """x: the operand, or a callable that makes it on the launching stream; keep: tensors the callable reads (kept alive, and
+        recorded on the side stream)"""
         dev = dy.device
+        k = keep[0].shape[1] if callable(x) else x.shape[1]
         if dw is None:
-            dw = torch.empty(dy.shape[1], x.shape[1], dtype=torch.float32, device=dev)
+            dw = torch.empty(dy.shape[1], k, dtype=torch.float32, device=dev)
         if db is None:
             db = torch.empty(dy.shape[1], dtype=torch.float32, device=dev)
-        self.jobs.append((dy, x, dw, db))
+        self.jobs.append((dy, x, dw, db, keep))
         if post is not None:
             self.post.append(post)
         return dw, db
@@ -369,13 +376,13 @@ class _WgQueue:
         self.jobs, self.post = [], []
 
         def run():
-            ops.gemm_wgrad_group(jobs)
+            ops.gemm_wgrad_group([(dy, x() if callable(x) else x, dw, db) for dy, x, dw, db, _ in jobs])
             for fn in post:
                 fn()
         if self.side is None:
             run()
         else:
-            self.side.run(run, *[t for j in jobs for t in j[:2]])
+            self.side.run(run, *[t for j in jobs for t in (j[0], j[1], *j[4]) if isinstance(t, torch.Tensor)])
 
 
 def _ln_bwd(grads, G, name, dy, x, P, mean, rstd, g_in=None, fold=None):
@@ -697,12 +704,25 @@ def backward(cfg, P, W, dt, ctx, G=None, on_ready=None):
         dw, _ = ops.gemm_wgrad(g_lp, ctx["a_pe"], x_rows=ctx["src_row"], want_bias=False, dw=dw_out)
         db = ops.colsum_groups(g, 1, 1, sel=ctx["src_row"], sel_nonneg=True).reshape(-1)   # padded slots carry no bias
         _put(grads, G, bname, db)
-    elif queue is not None and dw_out is not None and ops.wgrad_group_eligible(g_lp, ctx["a_pe"]):
-        dw, grads[bname] = queue.add(g_lp, ctx["a_pe"], dw_out, G[bname])       # rides with the last block's qkv product
+    elif queue is not None and G is not None and ops.wgrad_group_eligible(g_lp, ctx["a_pe"]):
+        if dw_out is not None:
+            dw, grads[bname] = queue.add(g_lp, ctx["a_pe"], dw_out, G[bname])       # rides with the last block's products
+        else:       # channels-last patches: the columns come out in (py, px, c) order, one strided copy behind the launch puts them into G
+            tmp = torch.empty(wshape[0], wshape[1] * wshape[2] * wshape[3], dtype=torch.float32, device=g_lp.device)
+            if side is not None:
+                tmp.record_stream(side.stream)
+
+            def permute_into_g():
+                G[wname].copy_(tmp.reshape(wshape[0], wshape[2], wshape[3], wshape[1]).permute(0, 3, 1, 2))
+            _, grads[bname] = queue.add(g_lp, ctx["a_pe"], tmp, G[bname], post=permute_into_g)
+            grads[wname] = G[wname]
+            dw = None
     else:
         dw, db = ops.gemm_wgrad(g_lp, ctx["a_pe"], dw=dw_out, db=None if G is None else G[bname])
         grads[bname] = db
-    if ctx["channels_last"]:
+    if dw is None:
+        pass                                                                               # queued: the copy into G runs behind the grouped launch
+    elif ctx["channels_last"]:
         dw = dw.reshape(wshape[0], wshape[2], wshape[3], wshape[1]).permute(0, 3, 1, 2)    # strided view: ONE copy into G (or below)
         if G is None:
             dw = dw.contiguous()
