@@ -218,8 +218,11 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     import torch.distributed as dist
-    if world > 1:
+    if world > 1 or os.environ.get("STAR_AMD_FORCE_DP") == "1":
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29544")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         torch.cuda.set_device(local % torch.cuda.device_count())
         backend = os.environ.get("STAR_AMD_DIST_BACKEND", "nccl")   # "gloo": rehearsal of the N>1 flow where RCCL cannot run (ranks sharing one GPU)
         if backend == "nccl":
@@ -257,7 +260,9 @@ def main():
         model = getattr(mm, args.model)(time_stamp=args.time_stamp, mask_method=args.mask).to(dev).set_compute_dtype(args.dtype)
         opt = FlatAdamW(model, lr=1e-3, betas=(0.9, 0.95), weight_decay=0.05)
     model.train() if args.mode == "train" else model.eval()
-    par = SceneParallel(model, opt) if world > 1 else None
+    # STAR_AMD_FORCE_DP=1 (measurement): the data-parallel hooks and collectives with ONE rank (launch under torch.distributed.run)
+    force_dp = os.environ.get("STAR_AMD_FORCE_DP") == "1" and dist.is_initialized()
+    par = SceneParallel(model, opt, force=force_dp) if (world > 1 or force_dp) else None
     if par is not None:
         par.broadcast_parameters(0)
     cm = CoModule(model, opt, args.com, parallel=par)
@@ -381,7 +386,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline and args.com == "ind_mae":
             out["cpu_baseline"] = cpu_baseline(args, min(16, os.cpu_count() or 1))
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 

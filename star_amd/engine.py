@@ -346,6 +346,7 @@ def _wg(grads, G, name, dy, x, x_rows=None, side=None, wait=True, queue=None):
 # 4.0 ms beside it); finer groups 11.9.  The step time does not follow the kernel time: the 384-wide kernel is denser (2 waves per
 # SIMD at 218 registers, 96 KB of LDS) and shares a CU with the main chain less well than the small one did.
 # A data-parallel wrapper (on_ready) needs a stage's gradients complete at the stage's end: the queue is flushed there too.
+_DP_JOIN = os.environ.get("STAR_AMD_DP_JOIN", "0") == "1"
 WG_GROUP = os.environ.get("STAR_AMD_WGRAD_GROUP", "1") == "1"
 WG_FLUSH = os.environ.get("STAR_AMD_WGRAD_FLUSH", "block")
 _WG_FLUSH_AT = set(WG_FLUSH.split(","))       # any of: fc1 (after the fc1 product is queued), proj, attn, block
@@ -617,12 +618,24 @@ def backward(cfg, P, W, dt, ctx, G=None, on_ready=None):
     queue = _WgQueue(side) if WG_GROUP and dt == BF16 else None      # grouped launches (with or without a side stream)
 
     def end_stage(k, sd):
-        if on_ready is not None:
-            if queue is not None:
-                queue.flush()
-            if sd is not None:
-                sd.join()
+        """stage k's gradients are all enqueued: hand the stage to the data-parallel wrapper.  With a side stream the hand-over
+        runs ON the side stream (behind the stage's weight-gradient launches, and behind everything the main chain has enqueued
+        so far): the collective then waits for that stream, and the main chain is never made to wait for the weight gradients in
+        the middle of the backward (STAR_AMD_DP_JOIN=1: the round-2 behaviour, main joins the side stream at every stage)."""
+        if on_ready is None:
+            return
+        if queue is not None:
+            queue.flush()
+        if sd is None:
             on_ready(k)
+        elif _DP_JOIN:
+            sd.join()
+            on_ready(k)
+        else:
+            sd.stream.wait_stream(torch.cuda.current_stream(sd.device))
+            with torch.cuda.stream(sd.stream):
+                on_ready(k)
+            sd.used = True
 
     def heads_unpermute(dw, db):
         idx = head_permutation(cfg, dw.device, as_int64=True)
