@@ -21,6 +21,7 @@
 //   * Split-M in the TN kernel writes fp32 slabs reduced in a fixed order (deterministic gradients).
 // The fp32 path (STAR_F32) uses v_mfma_f32_16x16x4_f32 on the same skeleton with BK = 32.
 #include "common.h"
+#include <type_traits>
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
 typedef __attribute__((ext_vector_type(8))) short short8_t;
@@ -1365,121 +1366,179 @@ __device__ __forceinline__ void st_wt4(__amdgpu_buffer_rsrc_t rs, unsigned byte_
 }
 
 // Main loop of the grouped kernel: 8 waves as WKW (k) x 8/WKW (n); a wave owns AK x BN blocks of 16 x 16, so the tile is
-// TK = 16 AK WKW by TN = 16 BN (8/WKW).  A stage (32 rows of m) is a set of 128-column PANELS, each laid out exactly like one
-// operand tile of gemm_tn_fast_kernel ([32 rows][256 B], 32-byte slots XOR-swizzled): TN/128 panels of dY, then TK/128 of X.
-// Why wider tiles than 128 x 128: an LDS-DMA piece (1 KiB) costs the issuing wave ~60-190 cycles, as much as the 4 MFMAs it
-// feeds at 128 x 128; at 384 x 128 a piece feeds 6, at 256 x 256 8, and the fragment reads per MFMA drop from 1.5 to 0.8 / 0.75.
-// Fragment reads are issued for the whole stage and every MFMA row waits on a COUNTED lgkmcnt; rows r0 and r0 + 4 of a
-// fragment share their swizzle (r0 = 8 lg + lq, lq < 4), so the second read is the first plus offset:1024.
-template <int OFF> __device__ __forceinline__ star_short4_t tr16v(unsigned addr) { return tr16<OFF>(addr); }
+// TK = 16 AK WKW by TN = 16 BN (8/WKW).  What bounds this kernel is the rate at which a CU takes operand bytes in (LDS-DMA, ~60 GB/s per
+// CU measured with the MFMAs and fragment reads compiled out: tools/diag_wgroup.sh), so the tile is as large as the accumulators
+// allow: 384 x 192 (encoder widths) moves 0.75 of the bytes per flop of 384 x 128, 256 x 256 (decoder widths) half those of 128 x 128.
+// A stage (32 rows of m) is a set of 64-column PANELS [32 rows][128 B], TN/64 of dY then TK/64 of X; 32-byte slots are XOR-swizzled by
+// row bits 1 and 3, which makes the 32 lanes of a ds_read_b64_tr_b16 group (rows r0..r0+3 and r0+8..r0+11, four 8-byte pieces each)
+// hit 64 different banks.  An LDS-DMA piece is 8 rows x 128 B; wave w fills rows 8 (w & 3).. of the panels of its parity
+// (w >> 2), so the early half (waves 0-3) takes ceil(NP / 2) pieces per stage and the late half floor(NP / 2).
+// Rows r0 and r0 + 4 of a fragment share their swizzle, so the second read of a fragment is the first plus offset:512.
+#ifndef TN_DIAG
+#define TN_DIAG 0       // diagnostic builds (tools/diag_wgroup.sh): 1 no LDS-DMA in the loop, 2 no MFMAs, 4 no fragment reads, 8 no barriers,
+#endif                  // 16 LDS-DMA source columns unswizzled, 32 the halves take alternate panels instead of contiguous runs
+__device__ __forceinline__ int tp_swz(int row) { return ((row >> 1) & 1) | (((row >> 3) & 1) << 1); }
+__device__ __forceinline__ int tp_off(int row, int slot) { return row * 128 + ((slot ^ tp_swz(row)) << 5); }
 
 template <int NST, int WKW, int AK, int BN>
 __device__ __forceinline__ void tn_wide_mainloop(unsigned char* smem, const bf16_t* __restrict__ dY, const bf16_t* __restrict__ X, int M, int N,
                                                  int K, int n_blk, int k_blk, int m_begin, int m_end, bool do_bias_tile,
-                                                 f32x4_t (&acc)[AK][BN], f32x4_t (&accb)[BN]) {
-    constexpr int WNW = 8 / WKW, TK = 16 * AK * WKW, TN = 16 * BN * WNW, PY = TN / 128, PX = TK / 128, NP = PY + PX;
-    constexpr int PANEL = 32 * 256, STAGE = NP * PANEL, PF = NST - 1;
-    static_assert(TK % 128 == 0 && TN % 128 == 0, "tile sides are multiples of the 128-column panel");
-    static_assert(2 * (AK - 1) <= 15 && NP * PF <= 63, "counted waits");
+                                                 f32x4_t (&acc)[AK][BN], f32x4_t& accb) {
+    constexpr int WNW = 8 / WKW, TK = 16 * AK * WKW, TN = 16 * BN * WNW, PY = TN / 64, PX = TK / 64, NP = PY + PX;
+    constexpr int PANEL = 32 * 128, STAGE = NP * PANEL, NQ0 = (NP + 1) / 2, NQ1 = NP / 2;
+    static_assert(TK % 64 == 0 && TN % 64 == 0, "tile sides are multiples of the 64-column panel");
+    static_assert(NST >= 3 && NQ0 <= 31 && BN <= 16, "ring depth, counted waits, one bias accumulator");
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wk = wave % WKW, wn = wave / WKW;
     const int lg = lane >> 4, lq = (lane & 15) >> 2, lp = lane & 3;
+    const bool late = wave >= 4;
 
     __amdgpu_buffer_rsrc_t rsY = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(dY), 0, (unsigned)((long long)M * N * 2), 0x00020000);
     __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(X), 0, (unsigned)((long long)M * K * 2), 0x00020000);
-    // every wave fills rows 4 wave .. 4 wave + 3 of every panel: one 1 KiB piece per panel and stage
-    unsigned off[NP];
-    {
-        const int r = wave * 4 + (lane >> 4);
-        const int pc = lane & 15;
-        const int col = (((pc >> 1) ^ tn_swz(r)) << 4) + ((pc & 1) << 3);
-#pragma unroll
-        for (int q = 0; q < PY; ++q) off[q] = n_blk + q * 128 + col < N ? (unsigned)(((long long)(m_begin + r) * N + n_blk + q * 128 + col) * 2) : 0x80000000u;
-#pragma unroll
-        for (int q = 0; q < PX; ++q) off[PY + q] = k_blk + q * 128 + col < K ? (unsigned)(((long long)(m_begin + r) * K + k_blk + q * 128 + col) * 2) : 0x80000000u;
-    }
+    // piece q of this wave: panel q (waves 0-3) or NQ0 + q (waves 4-7).  Only the offsets of panel 0 of each operand are kept (an
+    // array of per-piece offsets indexed through the two halves' code paths ends up in scratch memory, and its reloads wait on vmcnt,
+    // i.e. on every LDS-DMA piece in flight)
+    const int dr = (wave & 3) * 8 + (lane >> 3);
+    const int dpc = lane & 7;
+    const int dcol = (TN_DIAG & 16) ? dpc * 8 : (((dpc >> 1) ^ tp_swz(dr)) << 4) + ((dpc & 1) << 3);
+    const int ncol = n_blk + dcol, kcol = k_blk + dcol;
+    const unsigned offY = (unsigned)(((long long)(m_begin + dr) * N + ncol) * 2);
+    const unsigned offX = (unsigned)(((long long)(m_begin + dr) * K + kcol) * 2);
     const unsigned stepY = 32u * N * 2, stepX = 32u * K * 2;
-    auto issue = [&](int st_) {
-        unsigned char* sb = smem + (st_ % NST) * STAGE + wave * 4 * 256;
+    auto issue_half = [&](auto H, int st_) {
+        constexpr int h = decltype(H)::value;
+        unsigned char* sb = smem + (st_ % NST) * STAGE + (wave & 3) * 1024;
+        const unsigned sy = st_ * stepY, sx = st_ * stepX;
 #pragma unroll
-        for (int q = 0; q < PY; ++q)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsY, (__attribute__((address_space(3))) void*)(sb + q * PANEL), 16, off[q] + st_ * stepY, 0, 0, 0);
-#pragma unroll
-        for (int q = 0; q < PX; ++q)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, (__attribute__((address_space(3))) void*)(sb + (PY + q) * PANEL), 16, off[PY + q] + st_ * stepX, 0, 0, 0);
+        for (int q = 0; q < NQ0; ++q) {
+            const int pnl = (TN_DIAG & 32) ? 2 * q + h : q + h * NQ0;
+            if (pnl >= NP) continue;
+            if (pnl < PY) {
+                const unsigned o = ncol + pnl * 64 < N ? offY + (unsigned)(pnl * 128) + sy : 0x80000000u;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsY, (__attribute__((address_space(3))) void*)(sb + pnl * PANEL), 16, o, 0, 0, 0);
+            } else {
+                const unsigned o = kcol + (pnl - PY) * 64 < K ? offX + (unsigned)((pnl - PY) * 128) + sx : 0x80000000u;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, (__attribute__((address_space(3))) void*)(sb + pnl * PANEL), 16, o, 0, 0, 0);
+            }
+        }
     };
+    auto issue = [&](int st_) {
+        if (late) issue_half(std::integral_constant<int, 1>{}, st_);
+        else issue_half(std::integral_constant<int, 0>{}, st_);
+    };
+    // wait until at most k stages of this wave's pieces are in flight
+    constexpr int PFD = NST - 1;        // stage s + PFD is issued while stage s is read (into the slot of stage s - 1)
+    static_assert(PFD >= 2 && PFD <= 3 && 2 * NQ0 <= 63, "counted waits");
+    auto wait_stages = [&](int k) {
+        if (late) {
+            if (k >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NQ1) : "memory");
+            else if (k == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NQ1) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else {
+            if (k >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NQ0) : "memory");
+            else if (k == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NQ0) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+    };
+    accb = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int b = 0; b < BN; ++b) {
-        accb[b] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    for (int b = 0; b < BN; ++b)
 #pragma unroll
         for (int a = 0; a < AK; ++a) acc[a][b] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-    }
     const bool do_bias = do_bias_tile && wk == 0;
-    const short one = (short)0x3F80;
-    const short8_t ones = (short8_t){one, one, one, one, one, one, one, one};
     const int r0 = lg * 8 + lq;
     int ax[AK], ay[BN];
 #pragma unroll
     for (int a = 0; a < AK; ++a) {
-        const int col = (wk * AK + a) * 16;
-        ax[a] = (PY + (col >> 7)) * PANEL + tn_off(r0, (col & 127) >> 4) + lp * 8;
+        const int cb = wk * AK + a;
+        ax[a] = (PY + (cb >> 2)) * PANEL + tp_off(r0, cb & 3) + lp * 8;
     }
 #pragma unroll
     for (int b = 0; b < BN; ++b) {
-        const int col = (wn * BN + b) * 16;
-        ay[b] = (col >> 7) * PANEL + tn_off(r0, (col & 127) >> 4) + lp * 8;
+        const int cb = wn * BN + b;
+        ay[b] = (cb >> 2) * PANEL + tp_off(r0, cb & 3) + lp * 8;
     }
     const unsigned lds_base = lds_u32(smem);
     const int nsteps = (m_end - m_begin + 31) / 32;
-    for (int s0 = 0; s0 < PF && s0 < nsteps; ++s0) issue(s0);
+    // PING-PONG: the two waves of a SIMD (w and w + 4) run half a step apart.  A step is two intervals between workgroup barriers;
+    // in each, one half of the waves runs its MFMAs while the other half issues its LDS-DMA pieces for two steps ahead and reads its
+    // fragments (an LDS-DMA piece costs its issuing wave 60-190 cycles; in step, both waves of a SIMD paid that together and then
+    // queued on the matrix pipe together).
+    //   interval 2s    : waves 0-3 load(s)      waves 4-7 compute(s-1)
+    //   interval 2s + 1: waves 0-3 compute(s)   waves 4-7 load(s)
+    // load(s) = issue stage s + PFD, read the fragments of stage s, wait for them (so that no read is in flight when the slot is refilled
+    // two intervals later); stage s + 1 has landed (counted vmcnt) before the barrier that opens interval 2s + 2.  Three ring slots.
+    for (int s0 = 0; s0 < PFD && s0 < nsteps; ++s0) issue(s0);
+    wait_stages(min(PFD, nsteps) - 1);
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (late) { __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); }
     for (int st = 0; st < nsteps; ++st) {
-        const int rem = min(nsteps - 1 - st, PF - 1);
-        if (rem >= 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * NP <= 63 ? 3 * NP : 63) : "memory");
-        else if (rem == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NP) : "memory");
-        else if (rem == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NP) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        if (st + PF < nsteps) issue(st + PF);
+        // ---- load interval
+        if (!(TN_DIAG & 1) && st + PFD < nsteps) issue(st + PFD);
         const unsigned sb = lds_base + (st % NST) * STAGE;
         short4_t xl[AK], xh[AK], yl[BN], yh[BN];
+        if (TN_DIAG & 4) {
 #pragma unroll
-        for (int b = 0; b < BN; ++b) {
-            yl[b] = tr16<0>(sb + ay[b]);
-            yh[b] = tr16<1024>(sb + ay[b]);
-        }
+            for (int b = 0; b < BN; ++b) asm volatile("" : "=v"(yl[b]), "=v"(yh[b]));
 #pragma unroll
-        for (int a = 0; a < AK; ++a) {
-            xl[a] = tr16<0>(sb + ax[a]);
-            xh[a] = tr16<1024>(sb + ax[a]);
+            for (int a = 0; a < AK; ++a) asm volatile("" : "=v"(xl[a]), "=v"(xh[a]));
+        } else {
+#pragma unroll
+            for (int b = 0; b < BN; ++b) {
+                yl[b] = tr16<0>(sb + ay[b]);
+                yh[b] = tr16<512>(sb + ay[b]);
+            }
+#pragma unroll
+            for (int a = 0; a < AK; ++a) {
+                xl[a] = tr16<0>(sb + ax[a]);
+                xh[a] = tr16<512>(sb + ax[a]);
+            }
         }
+        // stages st + 1 .. min(st + PFD, nsteps - 1) are in flight; st + 1 must have landed before the early half reads it
+        if (late) wait_stages(min(st + PFD, nsteps - 1) - (st + 1));       // ... one barrier from here
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int b = 0; b < BN; ++b) asm volatile("" : "+v"(yl[b]), "+v"(yh[b]));
+#pragma unroll
+        for (int a = 0; a < AK; ++a) asm volatile("" : "+v"(xl[a]), "+v"(xh[a]));
+        if (!(TN_DIAG & 8)) __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- compute interval
         short8_t fy[BN];
 #pragma unroll
-        for (int a = 0; a < AK; ++a) {
-            // outstanding reads allowed while row a runs: the X pairs of the rows behind it
-            asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(xl[a]), "+v"(xh[a]) : "n"(2 * (AK - 1 - a)));
-            if (a == 0) {
+        for (int b = 0; b < BN; ++b) fy[b] = (short8_t){yl[b][0], yl[b][1], yl[b][2], yl[b][3], yh[b][0], yh[b][1], yh[b][2], yh[b][3]};
+        if (TN_DIAG & 2) {
 #pragma unroll
-                for (int b = 0; b < BN; ++b) {
-                    asm volatile("" : "+v"(yl[b]), "+v"(yh[b]));
-                    fy[b] = (short8_t){yl[b][0], yl[b][1], yl[b][2], yl[b][3], yh[b][0], yh[b][1], yh[b][2], yh[b][3]};
-                }
+            for (int a = 0; a < AK; ++a) asm volatile("" :: "v"(xl[a]), "v"(xh[a]), "v"(fy[a % BN]));
+        } else {
+#pragma unroll
+            for (int a = 0; a < AK; ++a) {
+                const short8_t fxa = (short8_t){xl[a][0], xl[a][1], xl[a][2], xl[a][3], xh[a][0], xh[a][1], xh[a][2], xh[a][3]};
+#pragma unroll
+                for (int b = 0; b < BN; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, fxa), __builtin_bit_cast(bf16x8_t, fy[b]),
+                                                                        acc[a][b], 0, 0, 0);
             }
-            const short8_t fxa = (short8_t){xl[a][0], xl[a][1], xl[a][2], xl[a][3], xh[a][0], xh[a][1], xh[a][2], xh[a][3]};
-#pragma unroll
-            for (int b = 0; b < BN; ++b)
-                acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, fxa), __builtin_bit_cast(bf16x8_t, fy[b]),
-                                                                    acc[a][b], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);      // keeps the next row's wait behind this row's MFMAs (asm waits are free to move otherwise)
         }
-        if (do_bias) {
+        if (do_bias && !(TN_DIAG & 2)) {
+            // column sums of dY: the A operand of block b is ones in ROW b only, so the one accumulator collects block b's sums in its row b
+            // (lane group b >> 2, register b & 3)
 #pragma unroll
-            for (int b = 0; b < BN; ++b)
-                accb[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, ones), __builtin_bit_cast(bf16x8_t, fy[b]),
-                                                                  accb[b], 0, 0, 0);
+            for (int b = 0; b < BN; ++b) {
+                const short sel = (lane & 15) == b ? (short)0x3F80 : (short)0;
+                const short8_t rowb = (short8_t){sel, sel, sel, sel, sel, sel, sel, sel};
+                accb = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, rowb), __builtin_bit_cast(bf16x8_t, fy[b]), accb, 0, 0, 0);
+            }
         }
+        if (!late) wait_stages(min(st + PFD, nsteps - 1) - (st + 1));      // the early half reaches the barrier that opens stage st + 1's reads from here
+        __builtin_amdgcn_sched_barrier(0);
+        if (!(TN_DIAG & 8)) __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
     }
+    if (!late) { __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); }
 }
 
 template <int NST, int WKW, int AK, int BN>
@@ -1514,9 +1573,11 @@ __global__ __launch_bounds__(512) void gemm_tn_group_kernel(const TnGroupArgs g)
     const int wk = wave % WKW, wn = wave / WKW, lg = lane >> 4;
     float* const db = g.db[j];
     const bool do_bias_tile = db != nullptr && k_blk == 0;
-    f32x4_t acc[AK][BN], accb[BN];
+    f32x4_t acc[AK][BN], accb;
     tn_wide_mainloop<NST, WKW, AK, BN>(smem, g.dY[j], g.X[j], M, N, K, n_blk, k_blk, m_begin, m_end, do_bias_tile, acc, accb);
-    const bool bias_lane = do_bias_tile && wk == 0 && lg == 0;
+    // bias: lane group lg of the wk == 0 waves holds the column sums of blocks 4 lg .. 4 lg + 3 (register j = block & 3), column lane & 15
+    const bool bias_lane = do_bias_tile && wk == 0 && lg * 4 < BN;
+    const int bias_n0 = n_blk + wn * (BN * 16) + lg * 64 + (lane & 15);     // + 16 j
     const int S = g.S[j];
     const int ci = g.tile0[j] + t;
     if (S > 1) {
@@ -1529,7 +1590,8 @@ __global__ __launch_bounds__(512) void gemm_tn_group_kernel(const TnGroupArgs g)
         if (bias_lane) {
             __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(g.bpart + (size_t)split * g.bias_ld + g.bias0[j], 0, (unsigned)(N * 4), 0x00020000);
 #pragma unroll
-            for (int b = 0; b < BN; ++b) st_wt4(rsB, (unsigned)((n_blk + wn * (BN * 16) + b * 16 + (lane & 15)) << 2), accb[b][0]);
+            for (int jb = 0; jb < 4; ++jb)
+                if (lg * 4 + jb < BN) st_wt4(rsB, (unsigned)((bias_n0 + 16 * jb) << 2), accb[jb]);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
@@ -1547,46 +1609,63 @@ __global__ __launch_bounds__(512) void gemm_tn_group_kernel(const TnGroupArgs g)
         }
         __syncthreads();
         if (!s_last) return;
-        // the last ticket: fold the S partial tiles in split order, all of them read back (this workgroup's own one included:
-        // its accumulators are dead after the store, which keeps the kernel at the register footprint of its main loop)
-        const float* slab0 = g.slabs + ((size_t)g.work0[j] + (size_t)t * S) * (TK * TN);
-        for (int s = 0; s < S; ++s) {
-            const float* sl = slab0 + (size_t)s * (TK * TN);
-#pragma unroll
-            for (int a = 0; a < AK; ++a) {
-                f32x4_t v[BN];
-#pragma unroll
-                for (int b = 0; b < BN; ++b)
-                    v[b] = __builtin_nontemporal_load(reinterpret_cast<const f32x4_t*>(sl + ((((wave * AK + a) * BN + b) * 64 + lane) << 2)));
-#pragma unroll
-                for (int b = 0; b < BN; ++b) acc[a][b] = s == 0 ? v[b] : acc[a][b] + v[b];
-            }
-            if (bias_lane) {
-#pragma unroll
-                for (int b = 0; b < BN; ++b) {
-                    const float vb = __builtin_nontemporal_load(g.bpart + (size_t)s * g.bias_ld + g.bias0[j] + n_blk + wn * (BN * 16) + b * 16 + (lane & 15));
-                    accb[b][0] = s == 0 ? vb : accb[b][0] + vb;
-                }
-            }
-        }
+        // the last ticket: fold the S partial tiles in split order, all of them read back (this workgroup's own one included).  One
+        // block row of the tile at a time -- sum over the splits, store -- so that the fold needs BN accumulators, not AK x BN
     }
-    if (bias_lane) {
+    float* o = g.dW[j];
+    auto store_row = [&](int a, const f32x4_t (&v)[BN]) {
+        const int k0 = k_blk + wk * (AK * 16) + a * 16 + lg * 4;
+        if (k0 >= K) return;
 #pragma unroll
         for (int b = 0; b < BN; ++b) {
             const int n = n_blk + wn * (BN * 16) + b * 16 + (lane & 15);
-            if (n < N) db[n] = accb[b][0];
+            if (n < N) *reinterpret_cast<float4*>(o + (size_t)n * K + k0) = make_float4(v[b][0], v[b][1], v[b][2], v[b][3]);
         }
-    }
-    float* o = g.dW[j];
-#pragma unroll
-    for (int b = 0; b < BN; ++b) {
-        const int n = n_blk + wn * (BN * 16) + b * 16 + (lane & 15);
-        if (n >= N) continue;
-#pragma unroll
+    };
+    if (S > 1) {
+        const float* slab0 = g.slabs + ((size_t)g.work0[j] + (size_t)t * S) * (TK * TN);
+#pragma unroll 1
         for (int a = 0; a < AK; ++a) {
-            const int k0 = k_blk + wk * (AK * 16) + a * 16 + lg * 4;
-            if (k0 >= K) continue;
-            *reinterpret_cast<float4*>(o + (size_t)n * K + k0) = make_float4(acc[a][b][0], acc[a][b][1], acc[a][b][2], acc[a][b][3]);
+            // eight partial tiles' worth of this row in flight at a time (the loads are HBM-latency-bound: one round trip per chunk)
+            constexpr int SC = 8;
+            f32x4_t sum[BN];
+            for (int s0 = 0; s0 < S; s0 += SC) {
+                f32x4_t v[SC][BN];
+#pragma unroll
+                for (int c = 0; c < SC; ++c) {
+                    const float* sl = slab0 + (size_t)min(s0 + c, S - 1) * (TK * TN);
+#pragma unroll
+                    for (int b = 0; b < BN; ++b)
+                        v[c][b] = __builtin_nontemporal_load(reinterpret_cast<const f32x4_t*>(sl + ((((wave * AK + a) * BN + b) * 64 + lane) << 2)));
+                }
+#pragma unroll
+                for (int c = 0; c < SC; ++c) {
+                    if (s0 + c >= S) break;
+#pragma unroll
+                    for (int b = 0; b < BN; ++b) sum[b] = (s0 + c) == 0 ? v[c][b] : sum[b] + v[c][b];
+                }
+            }
+            store_row(a, sum);
+        }
+        if (bias_lane) {
+            for (int s = 0; s < S; ++s) {
+#pragma unroll
+                for (int jb = 0; jb < 4; ++jb) {
+                    if (lg * 4 + jb >= BN || bias_n0 + 16 * jb >= N) continue;
+                    const float vb = __builtin_nontemporal_load(g.bpart + (size_t)s * g.bias_ld + g.bias0[j] + bias_n0 + 16 * jb);
+                    accb[jb] = s == 0 ? vb : accb[jb] + vb;
+                }
+            }
+        }
+    } else {
+#pragma unroll
+        for (int a = 0; a < AK; ++a) store_row(a, acc[a]);
+    }
+    if (bias_lane) {
+#pragma unroll
+        for (int jb = 0; jb < 4; ++jb) {
+            const int n = bias_n0 + 16 * jb;
+            if (lg * 4 + jb < BN && n < N) db[n] = accb[jb];
         }
     }
 }
@@ -1781,35 +1860,38 @@ extern "C" int star_gemm_wgrad(const void* dY, const void* X, const int32_t* x_r
 // tile shapes of the grouped kernel: (waves along k, k blocks, n blocks per wave) -> TK x TN
 struct TnShape { int wkw, ak, bn, tk, tn; };
 static const TnShape TN_SHAPES[] = {
-    {2, 4, 2, 128, 128},     // 0: the tile of gemm_tn_fast_kernel
-    {4, 6, 4, 384, 128},     // 1: K a multiple of 384 (encoder widths 384 / 1536)
-    {4, 4, 4, 256, 128},     // 2: K a multiple of 256 (decoder widths 256 / 1024); A/B only, see wgrad_job_shape
-};    // (256 x 256 with 4 x 8 blocks per wave needs 128 accumulator registers beside 48 of fragments and spills)
+    {2, 4, 2, 128, 128},     // 0: any shape
+    {4, 6, 6, 384, 192},     // 1: K a multiple of 384 (encoder widths 384 / 1536): 144 accumulator registers per lane
+    {2, 8, 4, 256, 256},     // 2: K a multiple of 256 (decoder widths 256 / 1024): 128
+};
 
 // Tile shape and split count are functions of the JOB alone (never of what it shares a launch with), so a gradient's bits do not
 // depend on how the caller groups its products.
 static int wgrad_job_shape(const StarWgradJob& q) {
-    static const char* env = getenv("STAR_AMD_WGRAD_TILE");     // 0..2 forces a tile shape (A/B)
-    if (env && env[0] >= '0' && env[0] <= '2') return env[0] - '0';
-    // the 384-wide tile wherever it wastes nothing: alone on the chip an encoder block's four products take 215 us against 300 with
-    // 128 x 128 tiles; the 256 x 128 tile (decoder widths) measured SLOWER than 128 x 128 (169 vs 130 us: a decoder block's 24 tiles
-    // need a split of 11, whose partial tiles cost more than the wider tile saves)
-    return (q.K % 384 == 0 && q.N % 128 == 0) ? 1 : 0;
+    static const char* env = getenv("STAR_AMD_WGRAD_TILE");     // 0..2 forces a tile shape where it divides K (A/B)
+    int want = -1;
+    if (env && env[0] >= '0' && env[0] <= '2') want = env[0] - '0';
+    const bool ok1 = q.K % 384 == 0 && q.N >= 192, ok2 = q.K % 256 == 0 && q.N >= 256;
+    if (want == 0 || (want == 1 && ok1) || (want == 2 && ok2)) return want;
+    return ok1 ? 1 : (ok2 ? 2 : 0);
 }
-static int wgrad_job_splits(const StarWgradJob& q, const TnShape& T) {
-    // Row splits per job: 5 (STAR_AMD_WGRAD_SPLITS overrides, A/B), whatever the job's size -- equal splits give every workgroup of a
-    // launch the same number of rows, so a block's products finish together (splits in proportion to 1 / tiles, i.e. equal workgroup
-    // counts per product, measured 289 us against 219 for an encoder block: the launch waits for the long ones).  A transformer block
-    // is 36 tiles of 384 x 128 (encoder) or 48 of 128 x 128 (decoder): 180 / 240 workgroups, 3/4 of the CUs or a little under one per
-    // CU -- beside the main backward chain that measured the same step time as 7 splits (one workgroup per CU) with less partial-tile
-    // traffic (2 x 5 x 4 bytes per weight against 14 % of the operand bytes of an encoder block).
-    static int want = -1;
-    if (want < 0) {
-        const char* e = getenv("STAR_AMD_WGRAD_SPLITS");
-        want = e ? atoi(e) : 0;
-        if (want <= 0) want = 5;
+static int wgrad_job_splits(const StarWgradJob& q, int sh) {
+    // Row splits per job, by tile shape (STAR_AMD_WGRAD_SPLITS="s0,s1,s2" overrides, A/B), whatever the job's size -- equal splits
+    // give every workgroup of a launch the same number of rows, so a block's products finish together.  What the step pays for is
+    // CU-time (a workgroup owns its CU: 8 waves of ~220 registers), so the split is the smallest that still gives a launch a few
+    // workgroups per XCD: an encoder block is 24 tiles of 384 x 192 (x 8 = 192 workgroups), a decoder block 12 of 256 x 256 (x 8 = 96);
+    // the partial tiles the last workgroup of a tile adds up cost S x 4 bytes per weight, ~5 % of the operand bytes at S = 8.
+    static int want[3] = {-1, -1, -1};
+    if (want[0] < 0) {
+        int w[3] = {5, 8, 8};
+        if (const char* e = getenv("STAR_AMD_WGRAD_SPLITS")) {
+            int v[3] = {0, 0, 0};
+            const int n = sscanf(e, "%d,%d,%d", &v[0], &v[1], &v[2]);
+            for (int i = 0; i < 3; ++i) { const int x = i < n ? v[i] : (n >= 1 ? v[0] : 0); if (x > 0) w[i] = x; }
+        }
+        want[2] = w[2]; want[1] = w[1]; want[0] = w[0];
     }
-    int S = want;
+    int S = want[sh];
     const int max_s = q.M / (8 * 32);                          // at least 8 reduction stages per split
     if (S > max_s) S = max_s;
     if (S > 32) S = 32;
@@ -1827,7 +1909,7 @@ static int wgrad_group_plan(const StarWgradJob* jobs, int njobs, int sh, TnGroup
         a->dY[n] = (const bf16_t*)q.dY; a->X[n] = (const bf16_t*)q.X; a->dW[n] = q.dW; a->db[n] = q.db;
         a->M[n] = q.M; a->N[n] = q.N; a->K[n] = q.K;
         a->tiles_n[n] = cdiv(q.N, T.tn); a->tiles_k[n] = cdiv(q.K, T.tk);
-        const int S = wgrad_job_splits(q, T);
+        const int S = wgrad_job_splits(q, sh);
         a->S[n] = S;
         a->mper[n] = cdiv(cdiv(q.M, S), 32) * 32;      // the last split may come out short or empty (a zero partial tile)
         a->tile0[n] = tiles;
@@ -1909,7 +1991,7 @@ extern "C" int64_t star_gemm_wgrad_group_ws(const StarWgradJob* jobs, int njobs,
 
 template <int NST, int WKW, int AK, int BN>
 static void launch_tn_group(const TnGroupArgs& a, int work, hipStream_t s) {
-    constexpr int LDS = NST * (16 * AK * WKW + 16 * BN * (8 / WKW)) / 128 * 32 * 256;
+    constexpr int LDS = NST * (16 * AK * WKW + 16 * BN * (8 / WKW)) * 64;       // 32 rows x 2 B per column and stage
     if (LDS > 48 * 1024)    // per launch: the attribute belongs to the current device, and the call is cheap
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_group_kernel<NST, WKW, AK, BN>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     hipLaunchKernelGGL((gemm_tn_group_kernel<NST, WKW, AK, BN>), dim3(work), dim3(512), LDS, s, a);
@@ -1922,8 +2004,8 @@ extern "C" int star_gemm_wgrad_group(const StarWgradJob* jobs, int njobs, float*
     STAR_CHECK(ws && ws_floats >= need, "star_gemm_wgrad_group: workspace of %lld floats, %lld needed", (long long)ws_floats, (long long)need);
     STAR_CHECK((reinterpret_cast<uintptr_t>(ws) & 15) == 0, "star_gemm_wgrad_group: workspace must be 16-byte aligned");
     hipStream_t s = (hipStream_t)stream;
-    static const char* nst_env = getenv("STAR_AMD_WGRAD_NST");     // ring depth (A/B): 3 (default) or 4 stages
-    const bool deep = nst_env && nst_env[0] == '4';
+    static const char* nst_env = getenv("STAR_AMD_WGRAD_NST");     // ring depth (A/B): 4 stages (default: an encoder block alone 227 us
+    const bool deep = !(nst_env && nst_env[0] == '3');              // against 233, a decoder block 161 against 175) or 3
     float* next = ws + TN_GROUP_COUNTERS;
     // one launch per tile shape present (a block's four products share one); the launches run one after the other on the stream
     // and use the ticket counters in turn, their partial tiles side by side
@@ -1940,8 +2022,8 @@ extern "C" int star_gemm_wgrad_group(const StarWgradJob* jobs, int njobs, float*
         next += (n + 3) / 4 * 4;
         const int work = a.table_n > 0 ? a.table_n : a.work0[a.njobs];
         switch (sh) {
-            case 1: if (deep) launch_tn_group<4, 4, 6, 4>(a, work, s); else launch_tn_group<3, 4, 6, 4>(a, work, s); break;
-            case 2: if (deep) launch_tn_group<4, 4, 4, 4>(a, work, s); else launch_tn_group<3, 4, 4, 4>(a, work, s); break;
+            case 1: if (deep) launch_tn_group<4, 4, 6, 6>(a, work, s); else launch_tn_group<3, 4, 6, 6>(a, work, s); break;
+            case 2: if (deep) launch_tn_group<4, 2, 8, 4>(a, work, s); else launch_tn_group<3, 2, 8, 4>(a, work, s); break;
             default: if (deep) launch_tn_group<4, 2, 4, 2>(a, work, s); else launch_tn_group<3, 2, 4, 2>(a, work, s); break;
         }
         STAR_LAUNCH_CHECK("star_gemm_wgrad_group");

@@ -11,6 +11,37 @@ from .misc import NativeScalerWithGradNormCount as NativeScaler
 from .move_optim import optimizer_to
 
 
+class _HostTimes:
+    """STAR_AMD_HOST_TIMES=1 (measurement): host wall time between the marks of the fused training step, printed at exit."""
+
+    def __init__(self):
+        import os
+        self.on = os.environ.get("STAR_AMD_HOST_TIMES") == "1"
+        self.t, self.acc, self.n = None, {}, 0
+        if self.on:
+            import atexit
+            atexit.register(self.report)
+
+    def mark(self, name):
+        if not self.on:
+            return
+        import time
+        now = time.perf_counter()
+        if self.t is not None:
+            self.acc[name] = self.acc.get(name, 0.0) + now - self.t
+        self.t = now
+        self.n += name == "opt"
+
+    def report(self):
+        import sys
+        n = max(self.n, 1)
+        print("host ms per step: " + "  ".join("%s %.3f" % (k, 1e3 * v / n) for k, v in self.acc.items()) +
+              "   (fwd = from the previous step's optimizer launch to the end of this step's forward launches)", file=sys.stderr)
+
+
+_HOST_T = _HostTimes()
+
+
 class CoModule(object):
     def __init__(self, model, optimizer, com, parallel=None, graph_inference=False):
         """`parallel`: optional star_amd.parallel.SceneParallel (multi-GPU gradient averaging).
@@ -65,8 +96,11 @@ class CoModule(object):
             self._loss_host[0:1].copy_(loss.detach().reshape(1), non_blocking=True)
             self._loss_event.record()
             flag_event = self.parallel.nonfinite_flag_to(loss, self._loss_host[1:2]) if self.parallel is not None else None
+            _HOST_T.mark("fwd")
             loss.backward()
+            _HOST_T.mark("bwd")
             self._loss_event.synchronize()
+            _HOST_T.mark("sync")
             if flag_event is not None:
                 flag_event.synchronize()
             loss_value = float(self._loss_host[0])
@@ -84,6 +118,7 @@ class CoModule(object):
             if self.parallel is not None:
                 self.parallel.finish()
             self.optimizer.step()
+            _HOST_T.mark("opt")
         elif trainable:
             self.mae_loss_scaler(loss, self.optimizer, parameters=self.model.parameters(), update_grad=True)
             self.optimizer.zero_grad()
