@@ -140,7 +140,14 @@ typedef struct StarGemm {
     int32_t M, N, K;
     int32_t dt;
     int32_t flags;          /* STAR_GEMM_* */
+    int32_t conv;           /* 0, or STAR_GEMM_CONV3X3(log2w, log2h): a 3 x 3 convolution (padding 1) over channels-last images as ONE
+                               product -- A [M, K / 9] holds the pixels of H x W images (powers of two, M a multiple of H W), W is
+                               [N, 9 (K / 9)] with tap t = 3 (dy + 1) + (dx + 1) in columns t K/9 .., and k-block t of output row m reads
+                               the A row of pixel (y + dy, x + dx) of the same image, zeros outside.  bf16, K / 9 a multiple of 32,
+                               bias-only epilogue, no a_rows (nn.Conv2d of the ConvPred heads, mae_base.py:16-105; the data gradient is
+                               the same product over the output gradient with the taps reversed and the weights transposed) */
 } StarGemm;
+#define STAR_GEMM_CONV3X3(log2w, log2h) ((int32_t)(0x40000000 | (log2w) | ((log2h) << 5)))
 #define STAR_GEMM_RES_BY_AROW 1 /* residual row = A row % res_mod, and rows with a_rows[m] < 0 are written as zeros
                                    (encode_partial: the patch embedding of a zero-padded slot is a zero row) */
 #define STAR_GEMM_PRE_IS_GRAD 2 /* with ACT_GELU / ACT_RELU: `pre` receives act'(pre-activation), the factor the backward
@@ -163,8 +170,11 @@ int star_gemm_wgrad(const void* dY, const void* X, const int32_t* x_rows, float*
 /* Several weight gradients in ONE launch (the four Linears of a timm Block, mae_base.py:279-281,308-310, whose autograd
  * backward the reference runs as four separate addmm's): job j computes dW_j [N_j, K_j] = dY_j^T X_j and, when db_j is given,
  * db_j = column sums of dY_j, exactly as star_gemm_wgrad does for one product (bf16 operands, N and K multiples of 8, no row
- * gather, 16-byte aligned pointers, at most 2 GiB per operand).  Every job is cut into row splits and 128 x 128 or 384 x 128 output
- * tiles by ITS OWN shape only -- so its result has the same bits whatever it shares a launch with -- few enough that a block's
+ * gather, 16-byte aligned pointers, at most 2 GiB per operand).  A job with `tap` != 0 is one tap of a 3 x 3 convolution's weight
+ * gradient over channels-last images (mae_base.py:16-105, the ConvPred heads: nn.Conv2d(k=3, padding=1) backward): its rows are the
+ * pixels of H x W images (powers of two, M a multiple of H W), and row m of X is taken from the pixel (y + dy, x + dx) of the same
+ * image, zeros outside -- the gather is arithmetic inside the kernel, no row table (STAR_WGRAD_TAP packs dy, dx, log2 W, log2 H).
+ * Every job is cut into row splits and 128 x 128, 384 x 192 or 256 x 256 output tiles by ITS OWN shape only -- so its result has the same bits whatever it shares a launch with -- few enough that a block's
  * four products fill the chip together; the split partial tiles are folded inside the kernel in a fixed order (bitwise
  * reproducible results, no atomics on data).  Jobs of the two tile shapes go out as two launches.  ws: float32
  * [star_gemm_wgrad_group_ws(...)] (-1: the jobs are not eligible, see star_last_error); its first 4 KiB are ticket counters that
@@ -177,8 +187,9 @@ typedef struct StarWgradJob {
     float* dW;        /* [N, K] float32, written */
     float* db;        /* optional [N] float32, written */
     int32_t M, N, K;
-    int32_t reserved;
+    int32_t tap;      /* 0: X rows as they lie; else STAR_WGRAD_TAP(dy, dx, log2w, log2h) */
 } StarWgradJob;
+#define STAR_WGRAD_TAP(dy, dx, log2w, log2h) ((int32_t)(0x40000000 | ((dy) + 1) | (((dx) + 1) << 2) | ((log2w) << 4) | ((log2h) << 9)))
 int64_t star_gemm_wgrad_group_ws(const StarWgradJob* jobs, int njobs, int dt);
 int star_gemm_wgrad_group(const StarWgradJob* jobs, int njobs, float* ws, int64_t ws_floats, int dt, void* stream);
 

@@ -28,13 +28,13 @@ class StarGemm(C.Structure):
         ("res2", C.c_void_p), ("res2_div", C.c_int32), ("res2_mod", C.c_int32),
         ("aux", C.c_void_p), ("act", C.c_int32), ("pre", C.c_void_p), ("out_lp", C.c_void_p),
         ("out_f32", C.c_void_p), ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32), ("dt", C.c_int32),
-        ("flags", C.c_int32),
+        ("flags", C.c_int32), ("conv", C.c_int32),
     ]
 
 
 class StarWgradJob(C.Structure):
     _fields_ = [("dY", C.c_void_p), ("X", C.c_void_p), ("dW", C.c_void_p), ("db", C.c_void_p),
-                ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32), ("reserved", C.c_int32)]
+                ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32), ("tap", C.c_int32)]
 
 
 WGRAD_GROUP_MAX = 8

@@ -280,7 +280,9 @@ template <int CG> __device__ __forceinline__ int ntf_run_off(int lg, int a) {
 // SPL = 1 (dt = STAR_BF16X3): operands are bf16 PAIRS hi + lo (a row of A / W is [hi (K) | lo (K)], an out_lp row [hi (N) | lo (N)])
 // and every k-step runs three MFMA products hi*hi + lo*hi + hi*lo on the bf16 pipe -- float32-grade products (2^-17 per operand,
 // the lo*lo term of 2^-18 dropped) at 3 MFMAs for 2x the operand bytes.  A stage then holds the hi images followed by the lo images.
-template <int NST, int EPI, int WM, int WN, int RB, int CG, int SPL = 0>
+// CONV = 1 (g.conv): an implicit 3 x 3 convolution -- k-block t of an output pixel reads the A row of the pixel shifted by tap t (or
+// zeros outside the image), so the nine taps accumulate in the registers instead of nine launches through a float32 output.
+template <int NST, int EPI, int WM, int WN, int RB, int CG, int SPL = 0, int CONV = 0>
 __global__ __launch_bounds__(WM * WN * 64) __attribute__((amdgpu_waves_per_eu(SPL ? 2 : (WM * WN == 4 ? 3 : (RB == 8 ? 2 : 4)))))
 void gemm_nt_fast_kernel(const StarGemm g) {
     static_assert(CG == 4 || CG == 8, "column groups of 4 (float32 outputs) or 8 (bf16 outputs)");
@@ -302,13 +304,24 @@ void gemm_nt_fast_kernel(const StarGemm g) {
     int colA[2], colW[2];        // SPL: element column of the lane's 16-byte chunk inside a k-step (K % 32 != 0: the last step is cut)
     static_assert(NA <= 2 && NWP <= 2, "LDS-DMA offset tables hold two pieces");
     const bool a_plain = SPL && (g.flags & STAR_GEMM_A_PLAIN) != 0;
-    const long long lda = SPL && !a_plain ? 2LL * K : K, ldw = SPL ? 2LL * K : K;      // row pitch in elements
+    const int conv_kt = CONV ? K / 9 : K;                 // CONV: channels per tap
+    const int conv_kpt = conv_kt / NTF_BK;                // k-steps per tap
+    const int conv_lw = g.conv & 31, conv_lh = (g.conv >> 5) & 31;
+    int cm[2], cpx[2], cpy[2];                            // CONV: output pixel of the lane's row (-1 past M), its x and y
+    const long long lda = CONV ? conv_kt : (SPL && !a_plain ? 2LL * K : K), ldw = SPL ? 2LL * K : K;      // row pitch in elements
     auto dma_setup = [&](int m_blk, int n_blk) {
 #pragma unroll
         for (int j = 0; j < NA; ++j) {
             const int r = (wave * NA + j) * 16 + (lane >> 2);
             const int c = (lane & 3) ^ ntf_swz(r);
             const int m = m_blk + r;
+            if constexpr (CONV != 0) {
+                cm[j] = m < M ? m : -1;
+                cpx[j] = m & ((1 << conv_lw) - 1);
+                cpy[j] = (m >> conv_lw) & ((1 << conv_lh) - 1);
+                offA[j] = c * 16;
+                continue;
+            }
             long long src = -1;
             if (m < M) src = g.a_rows ? (long long)g.a_rows[m] : (long long)m;
             offA[j] = src >= 0 ? (unsigned)(src * lda * 2 + c * 16) : 0x7fffffffu;
@@ -330,10 +343,23 @@ void gemm_nt_fast_kernel(const StarGemm g) {
     auto issue = [&](int kt) {
         unsigned char* st = smem + (kt % NST) * STAGE;
         const unsigned kb = kt * (NTF_BK * 2);
+        if constexpr (CONV != 0) {
+            const int t = kt / conv_kpt, kk = kt - t * conv_kpt;
+            const int ty = (t * 11) >> 5;                     // t / 3 for t = 0..8
+            const int dy = ty - 1, dx = t - 3 * ty - 1;
+            const int shift = dy * (1 << conv_lw) + dx;
+#pragma unroll
+            for (int j = 0; j < NA; ++j) {
+                const bool ok = cm[j] >= 0 && (unsigned)(cpx[j] + dx) < (1u << conv_lw) && (unsigned)(cpy[j] + dy) < (1u << conv_lh);
+                const unsigned o = ok ? (unsigned)((long long)(cm[j] + shift) * conv_kt * 2) + offA[j] + (unsigned)(kk * (NTF_BK * 2)) : 0x7fffffffu;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (__attribute__((address_space(3))) void*)(st + (wave * NA + j) * 16 * 64), 16, o, 0, 0, 0);
+            }
+        } else {
 #pragma unroll
         for (int j = 0; j < NA; ++j)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (__attribute__((address_space(3))) void*)(st + (wave * NA + j) * 16 * 64), 16,
                                                      offA[j] + kb, 0, 0, 0);
+        }
 #pragma unroll
         for (int j = 0; j < NWP; ++j)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (__attribute__((address_space(3))) void*)(st + BM * 64 + (wave * NWP + j) * 16 * 64), 16,
@@ -972,6 +998,24 @@ static int launch_nt_fast(const StarGemm* g, hipStream_t s) {
     return 0;
 }
 
+// implicit 3 x 3 convolution: the 256 x 128 tile when it fills the chip, else 128 x 128; column groups by output type
+template <int WM, int WN, int RB, int CG>
+static void launch_nt_conv_geo(const StarGemm* g, hipStream_t s) {
+    constexpr int NST = 3, BM = WM * RB * 16, BN = WN * 64;
+    const int tiles = cdiv(g->M, BM) * cdiv(g->N, BN);
+    const size_t lds = (size_t)NST * (BM + BN) * 64;
+    static unsigned long long attr_done = 0;
+    if (lds > 48 * 1024 && star_once_per_device(attr_done))
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_fast_kernel<NST, EPI_LINEAR, WM, WN, RB, CG, 0, 1>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)lds);
+    hipLaunchKernelGGL((gemm_nt_fast_kernel<NST, EPI_LINEAR, WM, WN, RB, CG, 0, 1>), dim3(tiles), dim3(WM * WN * 64), lds, s, *g);
+}
+static void launch_nt_conv(const StarGemm* g, hipStream_t s) {
+    const bool big = (long long)cdiv(g->M, 256) * cdiv(g->N, 128) >= star_num_cus();
+    if (g->out_lp) { if (big) launch_nt_conv_geo<4, 2, 4, 8>(g, s); else launch_nt_conv_geo<2, 2, 4, 8>(g, s); }
+    else { if (big) launch_nt_conv_geo<4, 2, 4, 4>(g, s); else launch_nt_conv_geo<2, 2, 4, 4>(g, s); }
+}
+
 template <typename T, int TM, int TN>
 static int launch_nt(const StarGemm* g, hipStream_t s) {
     constexpr int BM = 32 * TM, BN = 32 * TN;
@@ -1006,6 +1050,18 @@ extern "C" int star_gemm(const StarGemm* g, void* stream) {
     STAR_CHECK(!g->res2 || (g->res2_div > 0 && g->res2_mod > 0), "star_gemm: res2 needs div/mod");
     if (g->M == 0) return 0;
     hipStream_t s = (hipStream_t)stream;
+    if (g->conv != 0) {
+        const int lw = g->conv & 31, lh = (g->conv >> 5) & 31;
+        STAR_CHECK((g->conv & 0x40000000) && lw + lh <= 30 && g->M % (1 << (lw + lh)) == 0, "star_gemm(conv): bad conv word 0x%x for M=%d (STAR_GEMM_CONV3X3)", g->conv, g->M);
+        STAR_CHECK(g->dt == STAR_BF16 && g->K % (9 * NTF_BK) == 0 && g->N % 16 == 0, "star_gemm(conv): bf16, K=%d a multiple of 288, N=%d of 16", g->K, g->N);
+        STAR_CHECK(!g->a_rows && !g->c_rows && !g->res && !g->res2 && !g->aux && !g->pre && g->act == STAR_ACT_NONE && g->flags == 0,
+                   "star_gemm(conv): bias-only epilogue, no row tables");
+        STAR_CHECK((long long)g->M * (g->K / 9) * 2 < 0x7fffffffLL && (long long)g->N * g->K * 2 < 0x7fffffffLL, "star_gemm(conv): operand over 2 GiB");
+        STAR_CHECK(((reinterpret_cast<uintptr_t>(g->A) | reinterpret_cast<uintptr_t>(g->W)) & 15) == 0, "star_gemm(conv): operands must be 16-byte aligned");
+        launch_nt_conv(g, s);
+        STAR_LAUNCH_CHECK("star_gemm(conv)");
+        return 0;
+    }
     const bool narrow = g->N <= 32;
     const bool fast_ok = g->dt == STAR_BF16 && !narrow && g->K % NTF_BK == 0 && g->N % 16 == 0 && (long long)g->N * g->K * 2 < 0x7fffffffLL &&
                          ((reinterpret_cast<uintptr_t>(g->A) | reinterpret_cast<uintptr_t>(g->W)) & 15) == 0;
@@ -1342,7 +1398,7 @@ struct TnGroupArgs {
     float* dW[STAR_WGRAD_GROUP_MAX];
     float* db[STAR_WGRAD_GROUP_MAX];
     int M[STAR_WGRAD_GROUP_MAX], N[STAR_WGRAD_GROUP_MAX], K[STAR_WGRAD_GROUP_MAX], mper[STAR_WGRAD_GROUP_MAX], S[STAR_WGRAD_GROUP_MAX];
-    int tiles_n[STAR_WGRAD_GROUP_MAX], tiles_k[STAR_WGRAD_GROUP_MAX], bias0[STAR_WGRAD_GROUP_MAX];
+    int tiles_n[STAR_WGRAD_GROUP_MAX], tiles_k[STAR_WGRAD_GROUP_MAX], bias0[STAR_WGRAD_GROUP_MAX], tap[STAR_WGRAD_GROUP_MAX];
     int tile0[STAR_WGRAD_GROUP_MAX + 1];     // first tile (= ticket counter) of job j
     int work0[STAR_WGRAD_GROUP_MAX + 1];     // first work item (= partial-tile slot) of job j: tiles x splits, job-major, split, tile
     int njobs, bias_ld;
@@ -1382,7 +1438,7 @@ __device__ __forceinline__ int tp_off(int row, int slot) { return row * 128 + ((
 
 template <int NST, int WKW, int AK, int BN>
 __device__ __forceinline__ void tn_wide_mainloop(unsigned char* smem, const bf16_t* __restrict__ dY, const bf16_t* __restrict__ X, int M, int N,
-                                                 int K, int n_blk, int k_blk, int m_begin, int m_end, bool do_bias_tile,
+                                                 int K, int n_blk, int k_blk, int m_begin, int m_end, bool do_bias_tile, int tap,
                                                  f32x4_t (&acc)[AK][BN], f32x4_t& accb) {
     constexpr int WNW = 8 / WKW, TK = 16 * AK * WKW, TN = 16 * BN * WNW, PY = TN / 64, PX = TK / 64, NP = PY + PX;
     constexpr int PANEL = 32 * 128, STAGE = NP * PANEL, NQ0 = (NP + 1) / 2, NQ1 = NP / 2;
@@ -1406,10 +1462,21 @@ __device__ __forceinline__ void tn_wide_mainloop(unsigned char* smem, const bf16
     const unsigned offY = (unsigned)(((long long)(m_begin + dr) * N + ncol) * 2);
     const unsigned offX = (unsigned)(((long long)(m_begin + dr) * K + kcol) * 2);
     const unsigned stepY = 32u * N * 2, stepX = 32u * K * 2;
+    // tap mode (one tap of a 3 x 3 convolution over channels-last images): the X row of pixel m is pixel (y + dy, x + dx), zeros outside
+    const bool tapped = tap != 0;
+    const int tdy = (tap & 3) - 1, tdx = ((tap >> 2) & 3) - 1, lw = (tap >> 4) & 31, lh = (tap >> 9) & 31;
+    const int tshift = tdy * (1 << lw) + tdx;
     auto issue_half = [&](auto H, int st_) {
         constexpr int h = decltype(H)::value;
         unsigned char* sb = smem + (st_ % NST) * STAGE + (wave & 3) * 1024;
-        const unsigned sy = st_ * stepY, sx = st_ * stepX;
+        const unsigned sy = st_ * stepY;
+        unsigned xo = offX + st_ * stepX;
+        if (tapped) {
+            const int m = m_begin + st_ * 32 + dr;
+            const unsigned px = (unsigned)((m & ((1 << lw) - 1)) + tdx), py = (unsigned)(((m >> lw) & ((1 << lh) - 1)) + tdy);
+            const bool ok = m < M && px < (1u << lw) && py < (1u << lh);
+            xo = ok ? (unsigned)(((long long)(m + tshift) * K + kcol) * 2) : 0x80000000u;
+        }
 #pragma unroll
         for (int q = 0; q < NQ0; ++q) {
             const int pnl = (TN_DIAG & 32) ? 2 * q + h : q + h * NQ0;
@@ -1418,7 +1485,7 @@ __device__ __forceinline__ void tn_wide_mainloop(unsigned char* smem, const bf16
                 const unsigned o = ncol + pnl * 64 < N ? offY + (unsigned)(pnl * 128) + sy : 0x80000000u;
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rsY, (__attribute__((address_space(3))) void*)(sb + pnl * PANEL), 16, o, 0, 0, 0);
             } else {
-                const unsigned o = kcol + (pnl - PY) * 64 < K ? offX + (unsigned)((pnl - PY) * 128) + sx : 0x80000000u;
+                const unsigned o = (kcol + (pnl - PY) * 64 < K && xo < 0x80000000u) ? xo + (unsigned)((pnl - PY) * 128) : 0x80000000u;
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, (__attribute__((address_space(3))) void*)(sb + pnl * PANEL), 16, o, 0, 0, 0);
             }
         }
@@ -1574,7 +1641,7 @@ __global__ __launch_bounds__(512) void gemm_tn_group_kernel(const TnGroupArgs g)
     float* const db = g.db[j];
     const bool do_bias_tile = db != nullptr && k_blk == 0;
     f32x4_t acc[AK][BN], accb;
-    tn_wide_mainloop<NST, WKW, AK, BN>(smem, g.dY[j], g.X[j], M, N, K, n_blk, k_blk, m_begin, m_end, do_bias_tile, acc, accb);
+    tn_wide_mainloop<NST, WKW, AK, BN>(smem, g.dY[j], g.X[j], M, N, K, n_blk, k_blk, m_begin, m_end, do_bias_tile, g.tap[j], acc, accb);
     // bias: lane group lg of the wk == 0 waves holds the column sums of blocks 4 lg .. 4 lg + 3 (register j = block & 3), column lane & 15
     const bool bias_lane = do_bias_tile && wk == 0 && lg * 4 < BN;
     const int bias_n0 = n_blk + wn * (BN * 16) + lg * 64 + (lane & 15);     // + 16 j
@@ -1892,6 +1959,7 @@ static int wgrad_job_splits(const StarWgradJob& q, int sh) {
         want[2] = w[2]; want[1] = w[1]; want[0] = w[0];
     }
     int S = want[sh];
+    if (q.M / 8192 > S) S = q.M / 8192;                        // long products (a convolution's pixels): ~256 reduction stages per split
     const int max_s = q.M / (8 * 32);                          // at least 8 reduction stages per split
     if (S > max_s) S = max_s;
     if (S > 32) S = 32;
@@ -1907,7 +1975,7 @@ static int wgrad_group_plan(const StarWgradJob* jobs, int njobs, int sh, TnGroup
         const StarWgradJob& q = jobs[j];
         if (wgrad_job_shape(q) != sh) continue;
         a->dY[n] = (const bf16_t*)q.dY; a->X[n] = (const bf16_t*)q.X; a->dW[n] = q.dW; a->db[n] = q.db;
-        a->M[n] = q.M; a->N[n] = q.N; a->K[n] = q.K;
+        a->M[n] = q.M; a->N[n] = q.N; a->K[n] = q.K; a->tap[n] = q.tap;
         a->tiles_n[n] = cdiv(q.N, T.tn); a->tiles_k[n] = cdiv(q.K, T.tk);
         const int S = wgrad_job_splits(q, sh);
         a->S[n] = S;
@@ -1970,6 +2038,11 @@ static int wgrad_group_check(const StarWgradJob* jobs, int njobs, int dt) {
         STAR_CHECK(q.M > 0 && q.N > 0 && q.K > 0 && q.N % 8 == 0 && q.K % 8 == 0, "star_gemm_wgrad_group: job %d: bad shape M=%d N=%d K=%d (N, K multiples of 8)", j, q.M,
                    q.N, q.K);
         STAR_CHECK((long long)q.M * q.N * 2 < 0x7fffffffLL && (long long)q.M * q.K * 2 < 0x7fffffffLL, "star_gemm_wgrad_group: job %d: operand over 2 GiB", j);
+        if (q.tap != 0) {
+            const int dy1 = q.tap & 3, dx1 = (q.tap >> 2) & 3, lw = (q.tap >> 4) & 31, lh = (q.tap >> 9) & 31;
+            STAR_CHECK((q.tap & 0x40000000) && dy1 <= 2 && dx1 <= 2 && lw + lh <= 30 && q.M % (1 << (lw + lh)) == 0,
+                       "star_gemm_wgrad_group: job %d: bad tap word 0x%x for M=%d (STAR_WGRAD_TAP; images of 2^%d x 2^%d pixels)", j, q.tap, q.M, lw, lh);
+        }
         STAR_CHECK(((reinterpret_cast<uintptr_t>(q.dY) | reinterpret_cast<uintptr_t>(q.X) | reinterpret_cast<uintptr_t>(q.dW)) & 15) == 0,
                    "star_gemm_wgrad_group: job %d: operands must be 16-byte aligned", j);
     }

@@ -12,12 +12,13 @@ shifts on the transposed weights; its weight gradient = nine star_gemm_wgrad tap
 Reference behaviour kept on purpose: fusion("sum") REPLACES the fused latent by {0, 1} through masked assignment, so no
 gradient reaches the encoder through a fused slot -- only agent slots >= num_agent (which keep their own features) pass one."""
 import math
+import os
 
 import torch
 
 from . import ops
 from ._lib import ACT_DRELU, ACT_RELU, BF16
-from .engine import _block_bwd, _blocks_fwd, _lin, _ln_bwd, _patch_weight, _put, _wg
+from .engine import WG_GROUP, _block_bwd, _blocks_fwd, _lin, _ln_bwd, _patch_weight, _put, _wg, _WgQueue
 
 BN_EPS, BN_MOMENTUM = 1e-5, 0.1
 _ROWS = {}
@@ -62,9 +63,32 @@ def _conv_weights(P, W, name, dt, ldo):
     return W.get(("conv", name, dt, ldo), w._version, build)
 
 
-def _conv3x3(x, taps, bias, rows, ldo):
-    """x dt [R, Cin] -> float32 [R, ldo]."""
+_CONV_FUSED = os.environ.get("STAR_AMD_CONV_FUSED", "1") != "0"     # 0: nine star_gemm taps through the float32 output (A/B)
+
+
+def _conv_fused_ok(dt, h, w, kin):
+    """star_gemm's implicit 3 x 3 convolution covers it: bf16, power-of-two images, input channels a multiple of 32"""
+    return _CONV_FUSED and dt == BF16 and h & (h - 1) == 0 and w & (w - 1) == 0 and kin % 32 == 0
+
+
+def _conv_weights_fused(P, W, name, dt, ldo):
+    """The tap matrices side by side: forward [ldo, 9 Cin] (tap t in columns t Cin ..) and, for the data gradient, [Cin, 9 ldo] with
+    the taps REVERSED (input pixel p collects from output pixel p - shift(t): the opposite tap's shift)."""
+    w = P[name + ".weight"]
+
+    def build():
+        taps, taps_t = _conv_weights(P, W, name, dt, ldo)
+        return (taps.permute(1, 0, 2).reshape(ldo, -1).contiguous(), taps_t.flip(0).permute(1, 0, 2).reshape(taps_t.shape[1], -1).contiguous())
+
+    return W.get(("conv_fused", name, dt, ldo), w._version, build)
+
+
+def _conv3x3(x, taps, bias, rows, ldo, fused=None, hw=None):
+    """x dt [R, Cin] -> float32 [R, ldo].  fused: the [ldo, 9 Cin] weight -> one launch (the taps accumulate in registers)."""
     out = torch.empty(x.shape[0], ldo, dtype=torch.float32, device=x.device)
+    if fused is not None:
+        ops.gemm(x, fused, bias=bias, want_lp=False, want_f32=True, out_f32=out, conv=hw)
+        return out
     for t in range(9):
         ops.gemm(x, taps[t], bias=bias if t == 0 else None, res=out if t > 0 else None, a_rows=rows[t], want_lp=False, want_f32=True,
                  out_f32=out)
@@ -89,7 +113,8 @@ def head_forward(P, W, pre, x, n, g, dt, training, save):
         h, w = 2 * h, 2 * w
         rows = conv_rows(n, h, w, x.device)
         taps, _ = _conv_weights(P, W, pre + "conv%d" % s, dt, ldo)
-        conv = _conv3x3(xu, taps, _pad_to(P[pre + "conv%d.bias" % s].detach(), ldo), rows, ldo)
+        fused = _conv_weights_fused(P, W, pre + "conv%d" % s, dt, ldo)[0] if _conv_fused_ok(dt, h, w, xu.shape[1]) else None
+        conv = _conv3x3(xu, taps, _pad_to(P[pre + "conv%d.bias" % s].detach(), ldo), rows, ldo, fused=fused, hw=(h, w))
         gamma, beta = _pad_to(P[pre + "bn%d.weight" % s].detach(), ldo), _pad_to(P[pre + "bn%d.bias" % s].detach(), ldo)
         rm, rv = P[pre + "bn%d.running_mean" % s], P[pre + "bn%d.running_var" % s]
         if training:
@@ -118,17 +143,30 @@ def head_backward(P, W, saved, d, n, dt, training, grads):
         grads[pre + "bn%d.weight" % s], grads[pre + "bn%d.bias" % s] = dgamma[:cout].clone(), dbeta[:cout].clone()
         rows = conv_rows(n, sv["h"], sv["w"], d.device)
         cin = sv["xu"].shape[1]
-        dws = []
-        for t in range(9):
-            dw, db = ops.gemm_wgrad(dconv, sv["xu"], x_rows=rows[t], want_bias=(t == 0))
-            dws.append(dw)
-            if t == 0:
-                grads[pre + "conv%d.bias" % s] = db[:cout].clone()
+        hh, ww = sv["h"], sv["w"]
+        if (dt == ops.BF16 and hh & (hh - 1) == 0 and ww & (ww - 1) == 0 and ops.wgrad_group_eligible(dconv, sv["xu"])
+                and os.environ.get("STAR_AMD_CONV_WGRAD_GROUP", "1") != "0"):
+            # the nine taps as grouped launches: the shifted-pixel gather is arithmetic inside the kernel (no row table)
+            dwt = torch.empty(9, ldo, cin, dtype=torch.float32, device=d.device)
+            db = torch.empty(ldo, dtype=torch.float32, device=d.device)
+            ops.gemm_wgrad_group([(dconv, sv["xu"], dwt[t], db if t == 0 else False, ops.wgrad_tap(t // 3 - 1, t % 3 - 1, hh, ww)) for t in range(9)])
+            dws = list(dwt)
+            grads[pre + "conv%d.bias" % s] = db[:cout].clone()
+        else:
+            dws = []
+            for t in range(9):
+                dw, db = ops.gemm_wgrad(dconv, sv["xu"], x_rows=rows[t], want_bias=(t == 0))
+                dws.append(dw)
+                if t == 0:
+                    grads[pre + "conv%d.bias" % s] = db[:cout].clone()
         grads[pre + "conv%d.weight" % s] = torch.stack(dws).reshape(3, 3, ldo, cin)[:, :, :cout].permute(2, 3, 0, 1).contiguous()
         _, tapsT = _conv_weights(P, W, pre + "conv%d" % s, dt, ldo)
         dxu = torch.empty(dconv.shape[0], cin, dtype=torch.float32, device=d.device)
-        for t in range(9):                              # input pixel p collects from output pixel p - shift(t): the opposite tap's table
-            ops.gemm(dconv, tapsT[t], res=dxu if t > 0 else None, a_rows=rows[8 - t], want_lp=False, want_f32=True, out_f32=dxu)
+        if _conv_fused_ok(dt, hh, ww, ldo) and cin % 16 == 0:
+            ops.gemm(dconv, _conv_weights_fused(P, W, pre + "conv%d" % s, dt, ldo)[1], want_lp=False, want_f32=True, out_f32=dxu, conv=(hh, ww))
+        else:
+            for t in range(9):                          # input pixel p collects from output pixel p - shift(t): the opposite tap's table
+                ops.gemm(dconv, tapsT[t], res=dxu if t > 0 else None, a_rows=rows[8 - t], want_lp=False, want_f32=True, out_f32=dxu)
         d = ops.upsample2x_bwd(dxu, n, sv["h"] // 2, sv["w"] // 2)
     return d
 
@@ -204,12 +242,14 @@ def backward(cfg, P, W, dt, ctx):
     n_frames = ba * T
     grads = {}
     save = ctx["save"]
+    # weight gradients of the Linears leave in grouped launches (star_gemm_wgrad_group), one per block, as in the individual model
+    queue = _WgQueue(None) if WG_GROUP else None
     d_yd = head_backward(P, W, ctx["hs_free"], ctx["dfree"], ba, dt, ctx["training"], grads)
     d_yd = d_yd + head_backward(P, W, ctx["hs_occ"], ctx["docc"], ba, dt, ctx["training"], grads)
     d_lp = d_yd if dt != BF16 else ops.cast(d_yd, dt)
     g, g_lp = _ln_bwd(grads, None, "decoder_norm", d_lp, ctx["xd"], P, ctx["mean_d"], ctx["rstd_d"])
     for s in reversed(save[cfg.depth:]):
-        g, g_lp = _block_bwd(g, g_lp, s, P, W, dt, grads)
+        g, g_lp = _block_bwd(g, g_lp, s, P, W, dt, grads, queue=queue)
     # forward_fusion backward: the thresholded rows are constants; slots that kept their own features pass the gradient on
     pt_rows = ctx["passthrough"].to(torch.bool).repeat_interleave(L)                 # [ba*L] index bookkeeping, no arithmetic
     dst_row, fill = ctx["dst_row"], ctx["fill"]
@@ -223,15 +263,19 @@ def backward(cfg, P, W, dt, ctx):
     if ctx["random_mode"]:
         gt[0] += gtok[0]
     _put(grads, None, "decoder_temp_embed", gt.reshape(1, T, 1, Dd))
-    _wg(grads, None, "decoder_embed", dye, ctx["z"])
+    _wg(grads, None, "decoder_embed", dye, ctx["z"], queue=queue)
     dz, _, _ = ops.gemm(dye, _lin(P, W, "decoder_embed", dt, True))
-    _wg(grads, None, "decompressor", dz, ctx["latent_lp"])
+    _wg(grads, None, "decompressor", dz, ctx["latent_lp"], queue=queue)
     dlat, _, _ = ops.gemm(dz, _lin(P, W, "decompressor", dt, True), act=ACT_DRELU, aux=ctx["latent_lp"])
-    _wg(grads, None, "compressor.0", dlat, ctx["y"], x_rows=ctx["src_row"])
+    _wg(grads, None, "compressor.0", dlat, ctx["y"], x_rows=ctx["src_row"], queue=queue)
+    if queue is not None:
+        queue.flush()
     dy, _, _ = ops.gemm(dlat, _lin(P, W, "compressor.0", dt, True), c_rows=ctx["src_row"], out_rows=n_frames * L)
     g, g_lp = _ln_bwd(grads, None, "norm", dy, ctx["x_enc"], P, ctx["mean_e"], ctx["rstd_e"])
     for s in reversed(save[:cfg.depth]):
-        g, g_lp = _block_bwd(g, g_lp, s, P, W, dt, grads)
+        g, g_lp = _block_bwd(g, g_lp, s, P, W, dt, grads, queue=queue)
+    if queue is not None:
+        queue.flush()
     wshape = P["patch_embed.proj.weight"].shape
     dw, db = ops.gemm_wgrad(g_lp, ctx["a_pe"])
     if ctx["channels_last"]:

@@ -187,8 +187,9 @@ def ln_fold_batch(tab, njobs, max_d):
 # ---------------------------------------------------------------------------------------------------
 def gemm(a, w, m=None, bias=None, act=ACT_NONE, res=None, res_mod=0, res2=None, res2_div=0, res2_mod=0, aux=None,
          a_rows=None, c_rows=None, out_rows=None, want_pre=False, want_lp=True, want_f32=False, out_f32=None, out_lp=None,
-         flags=0, dt=None):
+         flags=0, dt=None, conv=None):
     """C = epilogue(A[a_rows] @ W^T).  a [*, K], w [N, K] same dtype (bf16 or f32).
+    conv = (h, w): a [pixels, Cin] channels-last images, w [N, 9 Cin] tap-major: the 3 x 3 convolution (padding 1) as one product.
     dt = BF16X3: w [N, 2K] and a [*, 2K] are bf16 hi/lo pairs (a [*, K] plain bf16 with flags & GEMM_A_PLAIN), out_lp [rows, 2N].
     Returns (out_lp, out_f32, pre) -- entries not requested are None."""
     _cuda(a, w)
@@ -198,7 +199,13 @@ def gemm(a, w, m=None, bias=None, act=ACT_NONE, res=None, res_mod=0, res2=None, 
     wd = L.width(dt)
     k = w.shape[1] // wd
     n = w.shape[0]
-    assert a.shape[-1] == (k if (dt != BF16X3 or flags & GEMM_A_PLAIN) else 2 * k), (a.shape, w.shape, dt, flags)
+    cw = 0
+    if conv is not None:
+        ch, cwid = conv
+        assert ch & (ch - 1) == 0 and cwid & (cwid - 1) == 0 and a.shape[-1] * 9 == k and a_rows is None, (conv, a.shape, w.shape)
+        cw = 0x40000000 | (cwid.bit_length() - 1) | ((ch.bit_length() - 1) << 5)
+    else:
+        assert a.shape[-1] == (k if (dt != BF16X3 or flags & GEMM_A_PLAIN) else 2 * k), (a.shape, w.shape, dt, flags)
     if m is None:
         m = a_rows.numel() if a_rows is not None else a.shape[0]
     rows_out = out_rows if out_rows is not None else m
@@ -210,9 +217,9 @@ def gemm(a, w, m=None, bias=None, act=ACT_NONE, res=None, res_mod=0, res2=None, 
     assert not (want_pre and dt == BF16X3), "bf16x3 is a forward-only storage type"
     pre = torch.empty(rows_out, n, dtype=a.dtype, device=dev) if want_pre else None
     g = L.StarGemm(p(a), p(w), p(a_rows), p(c_rows), p(bias), p(res), res_mod, p(res2), res2_div, res2_mod, p(aux), act,
-                   p(pre), p(out_lp), p(out_f32), m, n, k, dt, flags)
+                   p(pre), p(out_lp), p(out_f32), m, n, k, dt, flags, cw)
     esz = a.element_size() * wd
-    nbytes = (m * k + n * k) * esz + rows_out * n * ((esz if out_lp is not None else 0) + (4 if out_f32 is not None else 0) +
+    nbytes = (m * (k // 9 if conv is not None else k) + n * k) * esz + rows_out * n * ((esz if out_lp is not None else 0) + (4 if out_f32 is not None else 0) +
                                                       (esz if pre is not None else 0)) + m * n * ((4 if res is not None else 0) +
                                                                                                  (esz if aux is not None else 0))
     with _timed("gemm_nt", 2.0 * m * n * k, float(nbytes)):   # algorithmic bytes: every operand and result once
@@ -251,9 +258,17 @@ def wgrad_group_eligible(dy, x, x_rows=None):
             dy.data_ptr() % 16 == 0 and x.data_ptr() % 16 == 0)
 
 
+def wgrad_tap(dy, dx, h, w):
+    """STAR_WGRAD_TAP of star_hip.h; h, w powers of two."""
+    assert h & (h - 1) == 0 and w & (w - 1) == 0 and -1 <= dy <= 1 and -1 <= dx <= 1
+    return 0x40000000 | (dy + 1) | ((dx + 1) << 2) | ((w.bit_length() - 1) << 4) | ((h.bit_length() - 1) << 9)
+
+
 def gemm_wgrad_group(jobs):
-    """jobs: [(dy [M,N] bf16, x [M,K] bf16, dw float32 [N,K] or None, db float32 [N] or None / False = no bias), ...] -> [(dw, db), ...].
-    One launch for all of them (star_gemm_wgrad_group); more than WGRAD_GROUP_MAX jobs go out in several launches."""
+    """jobs: [(dy [M,N] bf16, x [M,K] bf16, dw float32 [N,K] or None, db float32 [N] or None / False = no bias[, tap]), ...] -> [(dw, db), ...].
+    One launch for all of them (star_gemm_wgrad_group); more than WGRAD_GROUP_MAX jobs go out in several launches.
+    tap = wgrad_tap(dy, dx, h, w): the product of one tap of a 3 x 3 convolution over channels-last h x w images (x rows shifted by
+    (dy, dx) inside their image, zeros outside)."""
     out = []
     for lo in range(0, len(jobs), L.WGRAD_GROUP_MAX):
         part = jobs[lo:lo + L.WGRAD_GROUP_MAX]
@@ -261,7 +276,9 @@ def gemm_wgrad_group(jobs):
         flops = nbytes = 0.0
         dev = part[0][0].device
         res = []
-        for i, (dy, x, dw, db) in enumerate(part):
+        for i, job in enumerate(part):
+            dy, x, dw, db = job[:4]
+            tap = job[4] if len(job) > 4 else 0
             _cuda(dy, x)
             assert dy.dtype == torch.bfloat16 and x.dtype == dy.dtype and dy.is_contiguous() and x.is_contiguous() and dy.shape[0] == x.shape[0]
             m, n = dy.shape
@@ -274,7 +291,7 @@ def gemm_wgrad_group(jobs):
                 db = None
             assert dw.is_contiguous() and dw.numel() == n * k and dw.dtype == torch.float32
             assert db is None or (db.is_contiguous() and db.numel() == n and db.dtype == torch.float32)
-            arr[i] = L.StarWgradJob(p(dy), p(x), p(dw), p(db), m, n, k, 0)
+            arr[i] = L.StarWgradJob(p(dy), p(x), p(dw), p(db), m, n, k, tap)
             flops += 2.0 * m * n * k
             nbytes += float(m * (n + k) * 2 + n * k * 4)
             res.append((dw, db))

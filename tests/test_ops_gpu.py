@@ -328,6 +328,52 @@ def test_gemm_wgrad_group(shapes):
             assert torch.equal(dw_r, first[k][0]) and torch.equal(db_r, first[k][1])
 
 
+@pytest.mark.parametrize("n,h,w,cin,cout", [(3, 16, 32, 128, 32), (2, 32, 32, 64, 128), (20, 8, 8, 256, 48), (1, 64, 128, 32, 256)])
+def test_gemm_conv3x3(n, h, w, cin, cout):
+    """star_gemm's implicit 3 x 3 convolution (conv word: the nine taps as k-blocks of one product) against torch's conv2d in float64
+    on the same bf16-rounded operands; with and without bias, float32 and bf16 outputs."""
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(h * 7 + cin)
+    x = torch.randn(n, h, w, cin, generator=g).to(DEV).bfloat16()
+    wt = (torch.randn(cout, cin, 3, 3, generator=g) * (9 * cin) ** -0.5).to(DEV).bfloat16()
+    bias = torch.randn(cout, generator=g).to(DEV)
+    wf = wt.permute(0, 2, 3, 1).reshape(cout, 9 * cin).contiguous()          # [N, (ky, kx, c)]
+    want = F.conv2d(x.double().permute(0, 3, 1, 2), wt.double(), bias.double(), padding=1).permute(0, 2, 3, 1).reshape(n * h * w, cout)
+    lp, f32, _ = ops.gemm(x.reshape(n * h * w, cin), wf, bias=bias, want_lp=True, want_f32=True, conv=(h, w))
+    torch.testing.assert_close(f32.double(), want, rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(lp.double(), want, rtol=1e-2, atol=1e-2)
+    _, f32b, _ = ops.gemm(x.reshape(n * h * w, cin), wf, want_lp=False, want_f32=True, conv=(h, w))
+    torch.testing.assert_close(f32b.double(), want - bias.double(), rtol=1e-4, atol=1e-4)
+    with pytest.raises(RuntimeError):       # rows that are not whole images
+        ops.gemm(x.reshape(n * h * w, cin)[: n * h * w - 16], wf, want_lp=False, want_f32=True, conv=(h, w))
+
+
+@pytest.mark.parametrize("n,h,w,N,K", [(3, 16, 32, 32, 128), (2, 32, 32, 128, 256), (5, 8, 16, 256, 512), (2, 64, 64, 8, 64)])
+def test_gemm_wgrad_group_conv_taps(n, h, w, N, K):
+    """the nine taps of a 3 x 3 convolution's weight gradient as grouped jobs (tap mode: the shifted-pixel gather is arithmetic in
+    the kernel) against float64 over the explicit shifted-row table, and against star_gemm_wgrad's x_rows path."""
+    from star_amd.joint import conv_rows
+    g = torch.Generator().manual_seed(n * 100 + K)
+    M = n * h * w
+    dy = torch.randn(M, N, generator=g).to(DEV).bfloat16()
+    x = torch.randn(M, K, generator=g).to(DEV).bfloat16()
+    rows = conv_rows(n, h, w, DEV)
+    out = ops.gemm_wgrad_group([(dy, x, None, None if t == 0 else False, ops.wgrad_tap(t // 3 - 1, t % 3 - 1, h, w)) for t in range(9)])
+    scale = math.sqrt(M)
+    for t in range(9):
+        r = rows[t].long()
+        xs = torch.where((r >= 0).unsqueeze(1), x[r.clamp(min=0)].double(), torch.zeros((), dtype=torch.float64, device=DEV))
+        torch.testing.assert_close(out[t][0].double() / scale, (dy.double().t() @ xs) / scale, rtol=1e-4, atol=1e-4)
+        dw1, _ = ops.gemm_wgrad(dy, x, x_rows=rows[t], want_bias=False)
+        torch.testing.assert_close(out[t][0], dw1, rtol=1e-5, atol=1e-3 * scale / 64)
+    torch.testing.assert_close(out[0][1].double() / scale, dy.double().sum(0) / scale, rtol=1e-4, atol=1e-4)
+    assert all(o[1] is None for o in out[1:])
+    again = ops.gemm_wgrad_group([(dy, x, None, False, ops.wgrad_tap(t // 3 - 1, t % 3 - 1, h, w)) for t in (4, 0, 8)])
+    assert torch.equal(again[0][0], out[4][0]) and torch.equal(again[1][0], out[0][0]) and torch.equal(again[2][0], out[8][0])
+    with pytest.raises(RuntimeError):       # rows that are not whole images
+        ops.gemm_wgrad_group([(dy[: M - 32], x[: M - 32], None, False, ops.wgrad_tap(0, 0, h, w))])
+
+
 def test_gemm_wgrad_group_rejects():
     dy, x = torch.zeros(64, 16, device=DEV), torch.zeros(64, 16, device=DEV)      # float32 operands
     with pytest.raises((RuntimeError, AssertionError)):

@@ -70,6 +70,30 @@ def wgrad_cases():
     return rows
 
 
+def conv_cases():
+    """the ConvPred head's three 3 x 3 convolutions at 20 frames (joint model, B = 4): forward, data gradient, weight gradient."""
+    g = torch.Generator().manual_seed(0)
+    rows = []
+    n = int(os.environ.get("FRAMES", 20))
+    for name, h, cin, cout in [("conv1 64^2 ", 64, 512, 256), ("conv2 128^2", 128, 256, 128), ("conv3 256^2", 256, 128, 32)]:
+        R = n * h * h
+        x = torch.randn(R, cin, generator=g).to(dev).bfloat16()
+        dy = torch.randn(R, cout, generator=g).to(dev).bfloat16()
+        wf = (torch.randn(cout, 9 * cin, generator=g) * (9 * cin) ** -0.5).to(dev).bfloat16()
+        wd = (torch.randn(cin, 9 * cout, generator=g) * (9 * cout) ** -0.5).to(dev).bfloat16()
+        out = torch.empty(R, cout, device=dev)
+        dx = torch.empty(R, cin, device=dev)
+        fl = 2.0 * R * 9 * cin * cout
+        us = timeit(lambda: ops.gemm(x, wf, want_lp=False, want_f32=True, out_f32=out, conv=(h, h)), n=5)
+        rows.append((name + " fwd", cout, 9 * cin, us, fl / us / 1e6, (R * cin * 2 + R * cout * 4) / us / 1e3))
+        us = timeit(lambda: ops.gemm(dy, wd, want_lp=False, want_f32=True, out_f32=dx, conv=(h, h)), n=5)
+        rows.append((name + " dgrad", cin, 9 * cout, us, fl / us / 1e6, (R * cout * 2 + R * cin * 4) / us / 1e3))
+        dwt = torch.empty(9, cout, cin, device=dev)
+        us = timeit(lambda: ops.gemm_wgrad_group([(dy, x, dwt[t], False, ops.wgrad_tap(t // 3 - 1, t % 3 - 1, h, h)) for t in range(9)]), n=5)
+        rows.append((name + " wgrad", cout, cin, us, fl / us / 1e6, (R * cout * 2 + R * cin * 2) / us / 1e3))
+    return rows
+
+
 def wgroup_cases():
     """a block's four weight gradients: one grouped launch against the four separate ones."""
     g = torch.Generator().manual_seed(0)
@@ -188,6 +212,6 @@ def vq_cases():
 if __name__ == "__main__":
     which = sys.argv[1:] or ["gemm", "wgrad", "wgroup", "attn", "ln", "voxel", "vq"]
     for w in which:
-        rows = dict(gemm=gemm_cases, gemm_ln=gemm_ln_cases, wgrad=wgrad_cases, wgroup=wgroup_cases, attn=attn_cases, ln=ln_cases, voxel=voxel_cases, vq=vq_cases)[w]()
+        rows = dict(gemm=gemm_cases, gemm_ln=gemm_ln_cases, wgrad=wgrad_cases, wgroup=wgroup_cases, conv=conv_cases, attn=attn_cases, ln=ln_cases, voxel=voxel_cases, vq=vq_cases)[w]()
         for name, a, b, us, tf, gbs in rows:
             print("%-26s %5d %5d  %8.1f us  %7.1f TFLOP/s  %7.1f GB/s(or Gexp/s)" % (name, a, b, us, tf, gbs))
