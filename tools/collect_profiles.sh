@@ -18,7 +18,12 @@ echo "pmc mfma done"
 : > $out/bench_other_configs.jsonl
 for flags in "--dtype fp32" "--mode infer --batch 16" "--mode infer --batch 16 --dtype bf16x3" "--mode infer --batch 16 --dtype fp32" "--mode infer --batch 1" "--mode infer --batch 1 --dtype bf16x3" "--mode infer --batch 1 --dtype fp32" \
              "--time_stamp 3" "--time_stamp 3 --mask random --mask_ratio 0.75" "--time_stamp 3 --mask random --mask_ratio 0.9" \
-             "--time_stamp 2 --mask random --mask_ratio 0.9" "--com vqstar"; do
+             "--time_stamp 2 --mask random --mask_ratio 0.9" "--com vqstar" \
+             "--model amortized_joint_patch8_shallow --batch 4 --steps 10" "--model amortized_joint_patch8_shallow --batch 4 --mode infer --steps 10"; do
   timeout -k 10 200 python bench.py --no-cpu-baseline --steps 20 --warmup 5 $flags >> $out/bench_other_configs.jsonl 2>> $out/bench_other.err || exit 1
   echo "config done: $flags"
 done
+# the grouped weight-gradient and convolution kernels alone, and the grouped kernel's HBM-side traffic
+timeout -k 10 200 python tools/bench_ops.py wgroup conv > $out/bench_ops_wgroup_conv.txt 2>&1 || exit 1
+bash tools/pmc_wgroup.sh > $out/pmc_wgroup_summary.txt 2>&1 || { tail -5 $out/pmc_wgroup_summary.txt; exit 1; }
+echo "wgroup done"
