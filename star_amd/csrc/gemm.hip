@@ -251,6 +251,9 @@ __global__ __launch_bounds__(GT) void gemm_nt_kernel(const StarGemm g) {
 // Epilogue: accumulators are staged through the (now idle) ring as fp32 [64][132] twice, so that bias /
 // activation / residual / row-scatter run on whole rows with 16-byte coalesced global accesses.
 #define NTF_BK 32
+#ifndef NT_DIAG
+#define NT_DIAG 0       // diagnostic builds (tools/diag_nt.sh; results WRONG, timing only): 1 no LDS-DMA in the loop, 2 no MFMAs, 4 no result stores
+#endif
 __device__ __forceinline__ int ntf_swz(int row) { return (0x78 >> (((row >> 2) & 3) << 1)) & 3; }
 
 // EPI specialises the epilogue at compile time (the fully general one costs ~10k instructions and spills):
@@ -566,7 +569,7 @@ void gemm_nt_fast_kernel(const StarGemm g) {
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
-            if (kt + PF < nk) issue_any(kt + PF, nk);
+            if (!(NT_DIAG & 1) && kt + PF < nk) issue_any(kt + PF, nk);
             const unsigned char* st = smem + (kt % NST) * STAGE;
             short8_t w8[4], x8[RB];
 #pragma unroll
@@ -590,12 +593,17 @@ void gemm_nt_fast_kernel(const StarGemm g) {
                                                                             acc[a][b], 0, 0, 0);
                     }
             }
+            if (NT_DIAG & 2) {
+#pragma unroll
+                for (int a = 0; a < 4; ++a) asm volatile("" ::"v"(w8[a]), "v"(x8[a % RB]));
+            } else {
 #pragma unroll
             for (int a = 0; a < 4; ++a)
 #pragma unroll
                 for (int b = 0; b < RB; ++b)
                     acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, w8[a]), __builtin_bit_cast(bf16x8_t, x8[b]),
                                                                         acc[a][b], 0, 0, 0);
+            }
         }
 
         // ---- hand the ring to the next tile before the epilogue
@@ -715,6 +723,7 @@ void gemm_nt_fast_kernel(const StarGemm g) {
 #pragma unroll
                 for (int e = 0; e < 16; ++e) v[e] += t2[e];
             }
+            if ((NT_DIAG & 4) && v[0] != 12345.678f) continue;       // diagnostic: no result stores
             if (out_lp) st_runs_lp(out_lp + (size_t)d * (SPL ? 2 * N : N), v);
             if (g.out_f32) st_runs(g.out_f32 + (size_t)d * N, v);
         }
@@ -737,7 +746,17 @@ static void launch_nt_fast_cg(const StarGemm* g, hipStream_t s) {
     // The kernel can walk several tiles per block (grid < tiles), prefilling the next tile's ring under the epilogue.
     // Measured on MI355X this is no faster than one tile per block, so every tile gets its own block and the hardware
     // dispatcher balances the tail.
-    hipLaunchKernelGGL((gemm_nt_fast_kernel<NST, EPI, WM, WN, RB, CG>), dim3(tiles), dim3(WM * WN * 64), lds, s, *g);
+    int grid = tiles;
+    static const char* penv = getenv("STAR_AMD_GEMM_PERSIST");      // 1: resident workgroups walk the tiles (A/B)
+    if (penv && penv[0] == '1') {
+        int occ = (int)(160 * 1024 / lds);
+        const int by_waves = (WM * WN == 4 ? 3 : (RB == 8 ? 1 : 2));
+        if (occ > by_waves) occ = by_waves;
+        if (occ < 1) occ = 1;
+        const int resident = star_num_cus() * occ;
+        if (tiles > resident) grid = resident;
+    }
+    hipLaunchKernelGGL((gemm_nt_fast_kernel<NST, EPI, WM, WN, RB, CG>), dim3(grid), dim3(WM * WN * 64), lds, s, *g);
 }
 
 template <int NST, int EPI, int WM, int WN, int RB>
