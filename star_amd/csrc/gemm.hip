@@ -1978,10 +1978,12 @@ static int wgrad_job_splits(const StarWgradJob& q, int sh) {
         want[2] = w[2]; want[1] = w[1]; want[0] = w[0];
     }
     int S = want[sh];
-    if (q.M / 8192 > S) S = q.M / 8192;                        // long products (a convolution's pixels): ~256 reduction stages per split
+    // long products (a convolution's pixels): ~256 reduction stages per split up to 32 splits, ~512 beyond (up to 64)
+    if (q.M / 8192 > S) S = q.M / 8192 < 32 ? q.M / 8192 : 32;
+    if (q.M / 16384 > S) S = q.M / 16384;
     const int max_s = q.M / (8 * 32);                          // at least 8 reduction stages per split
     if (S > max_s) S = max_s;
-    if (S > 32) S = 32;
+    if (S > 64) S = 64;
     if (S < 1) S = 1;
     return S;
 }
@@ -2017,7 +2019,7 @@ static int wgrad_group_plan(const StarWgradJob* jobs, int njobs, int sh, TnGroup
     static const char* tenv = getenv("STAR_AMD_WGRAD_PLACE");       // 0: plain job-major order through xcd_remap (A/B)
     if (n > 0 && !(tenv && tenv[0] == '0')) {
         struct Grp { int j, s, sz; };
-        Grp grp[STAR_WGRAD_GROUP_MAX * 32];
+        Grp grp[STAR_WGRAD_GROUP_MAX * 64];
         int ng = 0;
         for (int j = 0; j < n; ++j)
             for (int s2 = 0; s2 < a->S[j]; ++s2) grp[ng++] = {j, s2, a->tiles_n[j] * a->tiles_k[j]};
@@ -2027,7 +2029,7 @@ static int wgrad_group_plan(const StarWgradJob* jobs, int njobs, int sh, TnGroup
             while (q >= 0 && grp[q].sz < key.sz) { grp[q + 1] = grp[q]; --q; }
             grp[q + 1] = key;
         }
-        int load[8] = {0, 0, 0, 0, 0, 0, 0, 0}, owner[STAR_WGRAD_GROUP_MAX * 32];
+        int load[8] = {0, 0, 0, 0, 0, 0, 0, 0}, owner[STAR_WGRAD_GROUP_MAX * 64];
         for (int i = 0; i < ng; ++i) {
             int best = 0;
             for (int x = 1; x < 8; ++x) if (load[x] < load[best]) best = x;
