@@ -8,7 +8,7 @@ if [ "$1" = build ]; then
   mkdir -p $root/star_amd/diag
   for m in $masks; do
     ( cd $root/star_amd/csrc && /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=on -DNT_DIAG=$m -c gemm.hip -o build/gemm_n$m.o &&
-      /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../diag/libstar_hip_n$m.so $(ls build/*.o | grep -v "gemm\.o\|gemm_[dn]\|gemm_old") build/gemm_n$m.o ) &
+      /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../diag/libstar_hip_n$m.so $(ls build/*.o | grep -v "gemm\.o\|gemm_[dn]\|gemm_old\|gemm_ln_g") build/gemm_n$m.o ) &
   done
   wait
 else
