@@ -120,6 +120,33 @@ def test_joint_fixture_bf16_bounded(name):
         assert (num / den) ** 0.5 < 0.2, (num / den) ** 0.5
 
 
+@pytest.mark.parametrize("name", ["joint_T1_comp_train", "joint16_T3_comp_train"])
+def test_joint_conv_forms_agree(name, monkeypatch):
+    """bf16 mode: the one-launch convolution (star_gemm conv word) + grouped tap weight gradients against the nine-launch forms they
+    replace -- the same products summed in another order (registers instead of a float32 output), so loss and gradients agree far
+    inside the bf16 bounds above."""
+    from star_amd import joint
+    c = JointCase(name)
+    outs = []
+    for fused in (True, False):
+        monkeypatch.setattr(joint, "_CONV_FUSED", fused)
+        monkeypatch.setenv("STAR_AMD_CONV_WGRAD_GROUP", "1" if fused else "0")
+        m = build(c, "bf16")
+        loss, result, mask, pred = run(m, c)
+        loss.backward()
+        outs.append((loss.item(), pred.detach().float().cpu(), {k: p.grad.detach().cpu().clone() for k, p in m.named_parameters() if p.grad is not None}))
+    (l1, p1, g1), (l0, p0, g0) = outs
+    assert abs(l1 - l0) < 1e-4, (l1, l0)
+    assert (p1 - p0).pow(2).mean().sqrt() < 2e-2 * p0.pow(2).mean().sqrt()
+    num = den = 0.0
+    for k in g0:
+        if ".conv" in k and k.endswith(".weight"):
+            torch.testing.assert_close(g1[k], g0[k], rtol=5e-2, atol=5e-2 * g0[k].abs().max().item())
+        num += float((g1[k] - g0[k]).pow(2).sum())
+        den += float(g0[k].pow(2).sum())
+    assert (num / den) ** 0.5 < 3e-2, (num / den) ** 0.5
+
+
 def test_joint_full_size_factory_against_oracle():
     """amortized_joint_patch8_shallow (D = 768, 6 + 6 blocks, Dd = 512, ConvPred 512 -> 256 -> 128 -> 13 at 64/128/256 pixels)
     on one 3-agent scene with one empty agent slot, fp32 mode against the CPU oracle: features, thresholded latent, logits,
