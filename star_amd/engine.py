@@ -341,10 +341,9 @@ def _wg(grads, G, name, dy, x, x_rows=None, side=None, wait=True, queue=None):
 #   "block" (default) at the end of every block: its four products, one launch beside the next block's input-gradient GEMMs;
 #   "attn"  right before every attention backward (a block's fc2 / fc1 / proj products and the qkv product of the block before it);
 #   "fc1", "proj": after that product is queued (finer groups).
-# Measured inside one GPU call (B = 8 training step, round 3): separate launches + reduce kernels 11.52 ms (weight-gradient kernels
-# 5.3 ms of side-stream time, 90 launches); grouped "block" 11.65 ms (3.0 ms, 12 launches); "attn" 11.9 (attention backward 3.2 ->
-# 4.0 ms beside it); finer groups 11.9.  The step time does not follow the kernel time: the 384-wide kernel is denser (2 waves per
-# SIMD at 218 registers, 96 KB of LDS) and shares a CU with the main chain less well than the small one did.
+# Measured inside one GPU call (B = 8 training step, round 3, final kernel: 384 x 192 / 256 x 256 tiles): "block" 11.68-11.70 ms, "attn"
+# 11.67, "proj" 11.61 -- the step does not follow the flush point, the tile or the split count: what the
+# side stream overlaps stretches by what it takes.  The round-2 form (separate launches + reduce kernels, 90 launches) measured 11.52-11.57.
 # A data-parallel wrapper (on_ready) needs a stage's gradients complete at the stage's end: the queue is flushed there too.
 _DP_JOIN = os.environ.get("STAR_AMD_DP_JOIN", "0") == "1"
 WG_GROUP = os.environ.get("STAR_AMD_WGRAD_GROUP", "1") == "1"
