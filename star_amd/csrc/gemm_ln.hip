@@ -33,8 +33,10 @@ __device__ __forceinline__ int gl_run_off(int lg, int a) { return (a >> 1) * 32 
 template <int NST, int WM, int WN, int RB, int CB>
 __device__ __forceinline__ void gl_mainloop(const bf16_t* __restrict__ A, const bf16_t* __restrict__ W, int M, int K, int m_blk,
                                             unsigned char* smem, gl_f32x4_t (&acc)[CB][RB]) {
-    constexpr int NW = WM * WN, BM = WM * RB * 16, CW = CB * 16, N = WN * CW, NP = (BM + N) / 16, NDMA = NP / NW, STAGE = (BM + N) * 64, PF = NST - 1;
-    static_assert(NP % NW == 0 && NDMA <= 6, "the stage's 16-row pieces divide evenly over the waves");
+    // pieces are dealt round-robin (piece p to wave p % NW): when they do not divide evenly the first NP % NW waves carry one more
+    constexpr int NW = WM * WN, BM = WM * RB * 16, CW = CB * 16, N = WN * CW, NP = (BM + N) / 16, NDMA = (NP + NW - 1) / NW, NFULL = NP % NW,
+                  STAGE = (BM + N) * 64, PF = NST - 1;
+    static_assert(NDMA <= 6, "offset table");
     static_assert(PF >= 1 && PF <= 3 && PF * NDMA <= 63, "counted vmcnt");
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -42,10 +44,12 @@ __device__ __forceinline__ void gl_mainloop(const bf16_t* __restrict__ A, const 
     const int lr = lane & 15, lg = lane >> 4;
     __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(A), 0, 0x7fffffff, 0x00020000);
     __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(W), 0, 0x7fffffff, 0x00020000);
+    const bool short_wave = NFULL != 0 && wave >= NFULL;      // this wave has NDMA - 1 pieces per stage
     unsigned off[6];
 #pragma unroll
     for (int j = 0; j < NDMA; ++j) {
-        const int p = wave * NDMA + j;             // piece = stage rows p*16 .. +15 (A rows first, then the W image)
+        const int p = j * NW + wave;               // piece = stage rows p*16 .. +15 (A rows first, then the W image)
+        if (p >= NP) { off[j] = 0x7fffffffu; continue; }
         const int r = p * 16 + (lane >> 2);
         const int c = (lane & 3) ^ gl_swz(r);
         if (p < BM / 16) {
@@ -63,7 +67,8 @@ __device__ __forceinline__ void gl_mainloop(const bf16_t* __restrict__ A, const 
         const unsigned kb = kt * 64;
 #pragma unroll
         for (int j = 0; j < NDMA; ++j) {
-            const int p = wave * NDMA + j;
+            const int p = j * NW + wave;
+            if (p >= NP) continue;                  // (only the last j can be short: wave-uniform)
             auto dst = (__attribute__((address_space(3))) void*)(st + p * 1024);
             if (p < BM / 16) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, dst, 16, off[j] + kb, 0, 0, 0);
             else __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, dst, 16, off[j] + kb, 0, 0, 0);
@@ -84,9 +89,15 @@ __device__ __forceinline__ void gl_mainloop(const bf16_t* __restrict__ A, const 
     for (int s0 = 0; s0 < PF && s0 < nk; ++s0) issue(s0);
     for (int kt = 0; kt < nk; ++kt) {
         const int rem = min(nk - 1 - kt, PF - 1);   // stages allowed to stay in flight behind stage kt
-        if (rem >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NDMA) : "memory");
-        else if (rem == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (short_wave) {
+            if (rem >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (NDMA - 1)) : "memory");
+            else if (rem == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA - 1) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else {
+            if (rem >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NDMA) : "memory");
+            else if (rem == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         if (kt + PF < nk) issue(kt + PF);
@@ -106,7 +117,7 @@ __device__ __forceinline__ void gl_mainloop(const bf16_t* __restrict__ A, const 
 }
 
 template <int NST, int WM, int WN, int RB>
-__global__ __launch_bounds__(WM * WN * 64) __attribute__((amdgpu_waves_per_eu(WM * WN == 8 ? 4 : 3)))
+__global__ __launch_bounds__(WM * WN * 64) __attribute__((amdgpu_waves_per_eu(WM * WN == 8 ? (RB == 5 ? 2 : 4) : 3)))
 void gemm_res_ln_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ W, const float* __restrict__ bias,
                         const float* res, float* xout, const float* __restrict__ gamma, const float* __restrict__ beta,
                         bf16_t* __restrict__ h, float* __restrict__ mean, float* __restrict__ rstd, int M, int K, float eps) {
@@ -260,13 +271,18 @@ extern "C" int star_gemm_res_ln_supported(int N, int K, int dt) {
 //   N = 384: 192-row tiles (12 waves) once they cover 3/4 of the CUs; below that 96-row tiles (6 waves, two per CU) while K <= 512
 //            (they re-read the W panel twice as often: at K = 1536 they lose to star_gemm + star_layernorm_fwd);
 //   N = 256: 128-row tiles (8 waves) from half the CUs up, 64-row tiles (4 waves) below.
+//   160-row tiles (geometry 4) where they need fewer rounds x rows than the standard tile: a tile spans the row, so M alone sets the
+//   workgroup count, and M = 40 960 is 214 tiles of 192 rows (a sixth of the CUs idle) or 320 of 128 (two per CU on a quarter of
+//   them) but exactly 256 of 160.
 static int res_ln_geometry(int M, int N, int K) {
     const int cus = star_num_cus();
+    const long long r160 = (long long)cdiv(cdiv(M, 160), cus) * 160;
     if (N == 384) {
-        if (cdiv(M, 192) * 4 >= cus * 3) return 0;
+        if (cdiv(M, 192) * 4 >= cus * 3) return r160 < (long long)cdiv(cdiv(M, 192), cus) * 192 ? 4 : 0;
         return K <= 512 ? 1 : -1;
     }
-    return cdiv(M, 128) * 2 >= cus ? 0 : 1;
+    if (cdiv(M, 128) * 2 < cus) return 1;
+    return r160 < (long long)cdiv(cdiv(M, 128), 2 * cus) * 2 * 128 ? 4 : 0;
 }
 
 extern "C" int star_gemm_res_ln_prefers(int M, int N, int K, int dt) {
@@ -292,9 +308,11 @@ extern "C" int star_gemm_res_ln(const void* A, const void* W, const float* bias,
         if (geo == 1) rc = launch_res_ln<2, 1, 6, 6>(A, W, bias, res, x_out, gamma, beta, eps, h, mean, rstd, M, K, s);
         else if (geo == 2) rc = launch_res_ln<3, 1, 6, 6>(A, W, bias, res, x_out, gamma, beta, eps, h, mean, rstd, M, K, s);
         else if (geo == 3) rc = launch_res_ln<4, 2, 6, 6>(A, W, bias, res, x_out, gamma, beta, eps, h, mean, rstd, M, K, s);
+        else if (geo == 4) rc = launch_res_ln<3, 2, 6, 5>(A, W, bias, res, x_out, gamma, beta, eps, h, mean, rstd, M, K, s);
         else rc = launch_res_ln<3, 2, 6, 6>(A, W, bias, res, x_out, gamma, beta, eps, h, mean, rstd, M, K, s);
     } else {
         if (geo == 1) rc = launch_res_ln<3, 1, 4, 4>(A, W, bias, res, x_out, gamma, beta, eps, h, mean, rstd, M, K, s);
+        else if (geo == 4) rc = launch_res_ln<3, 2, 4, 5>(A, W, bias, res, x_out, gamma, beta, eps, h, mean, rstd, M, K, s);
         else rc = launch_res_ln<3, 2, 4, 4>(A, W, bias, res, x_out, gamma, beta, eps, h, mean, rstd, M, K, s);
     }
     if (rc) return rc;

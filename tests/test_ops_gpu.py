@@ -742,7 +742,7 @@ def test_gemm_res_ln_one_kernel_against_gemm_then_layernorm(m, n, k, monkeypatch
     assert ops.gemm_res_ln_supported(n, k, 0)
     _, x_ref, _ = ops.gemm(a, w, bias=bias, res=res, want_lp=False, want_f32=True)
     h_ref, mean_ref, rstd_ref = ops.layernorm_fwd(x_ref, gamma, beta, 1e-6, 0)
-    for geo in (None, "0", "1", "2", "3"):      # None: the library's own choice by shape
+    for geo in (None, "0", "1", "2", "3", "4"):      # None: the library's own choice by shape
         if geo is None:
             monkeypatch.delenv("STAR_AMD_GEMM_LN_GEO", raising=False)
         else:
