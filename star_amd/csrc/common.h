@@ -9,6 +9,8 @@
 
 int star_set_error(int code, const char* fmt, ...);
 int star_num_cus();   // compute units of the current device (cached)
+struct StarGemm;
+int star_gemm_rows_try(const StarGemm* g, hipStream_t s);   // gemm_ln.hip: whole-row tiles for a plain narrow Linear; 0 = launched
 
 #define STAR_CHECK(cond, ...)                                  \
     do {                                                       \

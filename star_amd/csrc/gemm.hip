@@ -1006,6 +1006,7 @@ static int launch_nt_split(const StarGemm* g, hipStream_t s) {
 template <int NST>
 static int launch_nt_fast(const StarGemm* g, hipStream_t s) {
     const bool plain = !g->res2 && !g->aux && !g->pre && g->act == STAR_ACT_NONE;
+    if (plain && !g->res && star_gemm_rows_try(g, s) == 0) return 0;
     if (plain && !g->res && launch_nt_wreg<EPI_LINEAR>(g, s)) return 0;
     if (plain && !g->res) launch_nt_fast_epi<NST, EPI_LINEAR>(g, s);
     else if (plain) launch_nt_fast_epi<NST, EPI_RES>(g, s);

@@ -262,6 +262,79 @@ static int launch_res_ln(const void* A, const void* W, const float* bias, const 
     return 0;
 }
 
+// ------------------------------------------------------------------------------------------------------
+// The same whole-row tile for a PLAIN Linear with a narrow bf16 result (out = A W^T (+ bias)): the decoder's input-gradient GEMMs
+// (N = 256) come out as 320 tiles of 256 x 128 on the tiled kernel's 512 slots (62 %); 160-row whole-row tiles are 256, one per CU.
+// Reached through star_gemm (no entry point of its own): star_gemm_rows_try returns 0 when it has launched.
+template <int NST, int WM, int WN, int RB>
+__global__ __launch_bounds__(WM * WN * 64) __attribute__((amdgpu_waves_per_eu(WM * WN == 8 ? 2 : 3)))
+void gemm_rows_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ W, const float* __restrict__ bias, bf16_t* __restrict__ out,
+                      int M, int K) {
+    constexpr int BM = WM * RB * 16, N = WN * 64;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave % WM, wn = wave / WM;
+    const int lr = lane & 15, lg = lane >> 4;
+    const int m_blk = blockIdx.x * BM;
+    int coff[4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) coff[a] = wn * 64 + gl_run_off(lg, a);
+    gl_f32x4_t acc[4][RB];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        const gl_f32x4_t bv = bias ? *reinterpret_cast<const gl_f32x4_t*>(bias + coff[a]) : (gl_f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int b = 0; b < RB; ++b) acc[a][b] = bv;
+    }
+    gl_mainloop<NST, WM, WN, RB, 4>(A, W, M, K, m_blk, smem, acc);
+    const int row0 = wm * (RB * 16) + lr;
+#pragma unroll
+    for (int b = 0; b < RB; ++b) {
+        const int m = m_blk + row0 + b * 16;
+        if (m >= M) continue;
+        bf16_t* dst = out + (size_t)m * N;
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh)
+            *reinterpret_cast<uint4*>(dst + coff[2 * hh]) =
+                make_uint4(pack_bf16(acc[2 * hh][b][0], acc[2 * hh][b][1]), pack_bf16(acc[2 * hh][b][2], acc[2 * hh][b][3]),
+                           pack_bf16(acc[2 * hh + 1][b][0], acc[2 * hh + 1][b][1]), pack_bf16(acc[2 * hh + 1][b][2], acc[2 * hh + 1][b][3]));
+    }
+}
+
+template <int NST, int WM, int WN, int RB>
+static int launch_rows(const StarGemm* g, hipStream_t s) {
+    constexpr int BM = WM * RB * 16, N = WN * 64;
+    const size_t lds = (size_t)NST * (BM + N) * 64;
+    static unsigned long long attr_done = 0;
+    if (lds > 48 * 1024 && star_once_per_device(attr_done)) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_rows_kernel<NST, WM, WN, RB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return 1;
+    }
+    hipLaunchKernelGGL((gemm_rows_kernel<NST, WM, WN, RB>), dim3(cdiv(g->M, BM)), dim3(WM * WN * 64), lds, s, (const bf16_t*)g->A, (const bf16_t*)g->W, g->bias,
+                       (bf16_t*)g->out_lp, g->M, g->K);
+    return 0;
+}
+
+// 0 = launched; nonzero = not this kernel's case (the caller goes on to the tiled kernel).  STAR_AMD_GEMM_ROWS=0 disables (A/B).
+int star_gemm_rows_try(const StarGemm* g, hipStream_t s) {
+    static const char* env = getenv("STAR_AMD_GEMM_ROWS");
+    const int mode = env ? atoi(env) : 2;           // 2: N = 256 and 384 (default); 1: N = 256 only; 0: off
+    if (mode == 0) return 1;
+    if (g->dt != STAR_BF16 || !g->out_lp || g->out_f32 || g->pre || g->aux || g->res || g->res2 || g->a_rows || g->c_rows || g->act != STAR_ACT_NONE ||
+        g->flags != 0 || g->conv != 0)
+        return 1;
+    if (!(g->N == 256 || (g->N == 384 && mode >= 2)) || g->K % 32 != 0 || g->K < 64) return 1;
+    if ((long long)g->M * g->K * 2 >= 0x7fffffffLL) return 1;
+    if (((reinterpret_cast<uintptr_t>(g->A) | reinterpret_cast<uintptr_t>(g->W) | reinterpret_cast<uintptr_t>(g->out_lp) | reinterpret_cast<uintptr_t>(g->bias)) & 15) != 0)
+        return 1;
+    const int cus = star_num_cus();
+    const int t160 = cdiv(g->M, 160);
+    // only where the 160-row tiles fill the chip about evenly: at least 3/4 of the CUs in the last round
+    if (t160 < cus * 3 / 4 || (t160 % cus != 0 && t160 % cus < cus * 3 / 4)) return 1;
+    return g->N == 256 ? launch_rows<3, 2, 4, 5>(g, s) : launch_rows<3, 2, 6, 5>(g, s);
+}
+
 extern "C" int star_gemm_res_ln_supported(int N, int K, int dt) {
     return dt == STAR_BF16 && (N == 256 || N == 384) && K >= 32 && K % 32 == 0;
 }

@@ -374,6 +374,27 @@ def test_gemm_wgrad_group_conv_taps(n, h, w, N, K):
         ops.gemm_wgrad_group([(dy[: M - 32], x[: M - 32], None, False, ops.wgrad_tap(0, 0, h, w))])
 
 
+@pytest.mark.parametrize("m,n,k,bias", [(40960, 256, 256, False), (40960 - 37, 256, 1024, True), (81920, 256, 768, False), (40960, 384, 1152, False)])
+def test_gemm_rows_path(m, n, k, bias, monkeypatch):
+    """plain narrow Linears at large M go through the whole-row kernel (gemm_rows_kernel, reached inside star_gemm): against float64 and
+    against the tiled kernel (STAR_AMD_GEMM_ROWS is read once per process, so the tiled result comes from a wider problem's columns)."""
+    g = torch.Generator().manual_seed(m + k)
+    a = torch.randn(m, k, generator=g).to(DEV).bfloat16()
+    w = (torch.randn(n, k, generator=g) * k ** -0.5).to(DEV).bfloat16()
+    b = torch.randn(n, generator=g).to(DEV) if bias else None
+    out, _, _ = ops.gemm(a, w, bias=b)
+    ref = a[:4096].double() @ w.double().t() + (b.double() if bias else 0.0)
+    torch.testing.assert_close(out[:4096].double(), ref, rtol=1e-2, atol=1e-2)
+    ref_t = a[-512:].double() @ w.double().t() + (b.double() if bias else 0.0)
+    torch.testing.assert_close(out[-512:].double(), ref_t, rtol=1e-2, atol=1e-2)
+    # the tiled kernel on the same rows (a float32 output keeps it off the whole-row path): same products, float32 accumulation both ways
+    _, o32, _ = ops.gemm(a, w, bias=b, want_lp=False, want_f32=True)
+    if bias:        # the whole-row kernel starts its accumulators from the bias, the tiled one adds it last: one float32 rounding apart
+        torch.testing.assert_close(out.float(), o32, rtol=1e-2, atol=1e-2)
+    else:
+        assert torch.equal(out, o32.bfloat16())
+
+
 def test_gemm_wgrad_group_rejects():
     dy, x = torch.zeros(64, 16, device=DEV), torch.zeros(64, 16, device=DEV)      # float32 operands
     with pytest.raises((RuntimeError, AssertionError)):
