@@ -348,6 +348,7 @@ def _wg(grads, G, name, dy, x, x_rows=None, side=None, wait=True, queue=None):
 _DP_JOIN = os.environ.get("STAR_AMD_DP_JOIN", "0") == "1"
 WG_GROUP = os.environ.get("STAR_AMD_WGRAD_GROUP", "1") == "1"
 WG_FLUSH = os.environ.get("STAR_AMD_WGRAD_FLUSH", "block")
+_WG_TAIL_MAIN = os.environ.get("STAR_AMD_WGRAD_TAIL_MAIN", "1") == "1"
 _WG_FLUSH_AT = set(WG_FLUSH.split(","))       # any of: fc1 (after the fc1 product is queued), proj, attn, block
 
 
@@ -742,6 +743,10 @@ def backward(cfg, P, W, dt, ctx, G=None, on_ready=None):
     else:
         grads[wname] = G[wname] if G is not None else dw.reshape(wshape)
     if queue is not None:
+        # the patch embedding's product is the last of the backward and the main chain has nothing left to run: launched on the main stream
+        # it overlaps the first block's grouped launch (still running on the side stream) instead of queueing behind it
+        if _WG_TAIL_MAIN:
+            queue.side = None
         queue.flush()
     if fold is not None:
         fold.run()
