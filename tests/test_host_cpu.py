@@ -62,3 +62,33 @@ def test_out_of_scope_constructors_say_so():
         mm.joint_bev_mae_vit_base_patch8(time_stamp=1)
     with pytest.raises(NotImplementedError):
         mm.amortized_ind_patch8_light(time_stamp=1, mask_method="stripes")
+
+
+def test_tap_and_conv_words_match_the_header():
+    """ops.wgrad_tap / the conv word of ops.gemm are the STAR_WGRAD_TAP / STAR_GEMM_CONV3X3 macros of include/star_hip.h, and the ctypes
+    structs have the header's sizes (a field added to one side only would shift every argument behind it)."""
+    import ctypes as C
+    import os
+    import re
+    import subprocess
+    import tempfile
+    from star_amd import _lib as L
+    from star_amd import ops
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = r'''
+#include <stdio.h>
+#include "star_hip.h"
+int main(void) {
+    printf("%d %d %d %d %zu %zu\n", STAR_WGRAD_TAP(-1, 1, 6, 7), STAR_WGRAD_TAP(0, 0, 8, 8), STAR_GEMM_CONV3X3(6, 7), STAR_GEMM_CONV3X3(8, 8),
+           sizeof(StarGemm), sizeof(StarWgradJob));
+    return 0;
+}
+'''
+    with tempfile.TemporaryDirectory() as d:
+        open(os.path.join(d, "t.c"), "w").write(src)
+        subprocess.check_call(["gcc", "-I", os.path.join(root, "include"), os.path.join(d, "t.c"), "-o", os.path.join(d, "t")])
+        out = subprocess.check_output([os.path.join(d, "t")]).decode().split()
+    t1, t2, c1, c2, sg, sj = (int(x) for x in out)
+    assert ops.wgrad_tap(-1, 1, 128, 64) == t1 and ops.wgrad_tap(0, 0, 256, 256) == t2
+    assert (0x40000000 | 6 | (7 << 5)) == c1 and (0x40000000 | 8 | (8 << 5)) == c2
+    assert C.sizeof(L.StarGemm) == sg and C.sizeof(L.StarWgradJob) == sj
